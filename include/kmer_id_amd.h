@@ -1,0 +1,180 @@
+/*
+ * kmer_id_amd.h -- C ABI of libkmer_id_amd.so, the MI355X (gfx950) k-mer read
+ * classifier.  This is the drop-in boundary for the hot path of
+ * mmammel8/kmer_id: everything `process_read` (newkmer_10nx.cpp:452-617) does
+ * with the global hash table `ht` (:158-266), the global taxonomy `taxonomy`
+ * (:93-156) and the global counters `gcount/ucount/kmer_seen` (:61-64).
+ *
+ * The reference has no FFI of its own (it is one translation unit with global
+ * state), so each entry point below names the reference code it replaces.
+ * INTEGRATION.md shows the ~40-line patch that makes newkmer_10nx.cpp call
+ * these instead of its own loop.
+ *
+ * Conventions: plain C types only; every function returns KID_OK (0) or a
+ * negative kid_status; no exception crosses the boundary; the caller owns every
+ * buffer it passes; the library owns the handles until *_destroy.  There is NO
+ * CPU fallback: without a HIP device every compute entry point returns
+ * KID_ERR_NO_DEVICE.
+ */
+#ifndef KMER_ID_AMD_H
+#define KMER_ID_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum kid_status {
+    KID_OK = 0,
+    KID_ERR_ARG = -1,        /* bad argument (null pointer, size, offsets not monotone, start/stop outside read) */
+    KID_ERR_NOMEM = -2,      /* host or device allocation failed */
+    KID_ERR_HIP = -3,        /* a HIP runtime call failed; see kid_last_error() */
+    KID_ERR_TABLE_FULL = -4, /* more than 2^log2_slots - 32 entries: the reference prints
+                                "out of memory in table" and exit(1)s, newkmer_10nx.cpp:256-260 */
+    KID_ERR_TREE = -5,       /* parent[] has an out-of-range entry or a cycle (the reference would loop forever in msca) */
+    KID_ERR_NO_DEVICE = -6,  /* no usable HIP device */
+    KID_ERR_TARGET = -7,     /* a target id >= ntar (the reference would index gcount[] out of bounds) */
+    KID_ERR_IO = -8,         /* file could not be opened / gz error (reference: exit(255), newkmer_10nx.cpp:87-91) */
+    KID_ERR_FORMAT = -9,     /* input line >= 16 KiB (exit 255, :773) or qual shorter than seq (std::out_of_range, :727) */
+    KID_ERR_STATE = -10      /* call sequence error (e.g. classify after sample_end without reset) */
+} kid_status;
+
+/* option bits for kid_db_build*() */
+#define KID_FLAG_U_IS_T 1u    /* U/u is read as T: kmer_read_vf6.cpp:496-500,521-525 */
+#define KID_FLAG_HOST_BUILD 2u /* build the table on the host with the reference's sequential insert
+                                  order (exact cell geometry).  Implied when max_probes > 0. */
+
+typedef struct kid_db kid_db;         /* hash table + taxonomy, resident in one GPU's HBM */
+typedef struct kid_sample kid_sample; /* per-sample counters: gcount, seen-bitmap (-> ucount) */
+
+typedef struct kid_db_info {
+    int32_t ntar;        /* number of taxonomy nodes (MAXTAR, newkmer_10nx.cpp:45) */
+    int32_t k;           /* k-mer length (KSIZE, :43) */
+    int32_t log2_slots;  /* log2 of the table size (MAXHASH, :49) */
+    int32_t max_probes;  /* 0 = unbounded (10nx, vf6); 16 = kmer_read_m3.cpp:42,232 */
+    uint32_t flags;
+    int32_t device;
+    int32_t tree_depth;  /* deepest node (root = 0) */
+    int32_t host_built;  /* 1 if the sequential host builder produced the table */
+    uint64_t n_entries;  /* entries handed to the builder */
+    uint64_t n_occupied; /* cells with value != 0 */
+    uint64_t table_bytes;
+} kid_db_info;
+
+const char *kid_strerror(int status);
+const char *kid_last_error(void); /* thread-local detail of the last failure */
+int kid_device_count(int *count);
+
+/* ---- database ------------------------------------------------------------
+ * Replaces: Hashtable::Hashtable + HashClear + add_kmer (newkmer_10nx.cpp:173-180,
+ * 199-202, 235-263) and Tree1::Tree1 + add_edge (:101-116).
+ *   keys[i], targets[i]  the forward 2-bit keys and target ids in probes-file
+ *                        order, exactly what process_kmer (:619-661) hands to
+ *                        add_kmer; duplicates allowed, first one wins on lookup.
+ *   parent[ntar]         Tree1::parent after all add_edge calls (default 1 = root).
+ *   k                    KSIZE (1..31);  log2_slots  log2(MAXHASH) (6..34)
+ *   max_probes           0 or the MAXREPROBE of kmer_read_m3.cpp
+ *   device               HIP device ordinal
+ * Table cells are 16 B {u64 key, u32 target, u32 insertion ordinal+1}.           */
+int kid_db_build(const uint64_t *keys, const uint32_t *targets, uint64_t n,
+                 const int32_t *parent, int32_t ntar, int k, int log2_slots,
+                 int max_probes, uint32_t flags, int device, kid_db **out);
+/* same, keys/targets already resident on `device` (used by the synthetic bench DB) */
+int kid_db_build_device(const void *d_keys, const void *d_targets, uint64_t n,
+                        const int32_t *parent, int32_t ntar, int k, int log2_slots,
+                        int max_probes, uint32_t flags, int device, kid_db **out);
+int kid_db_get_info(const kid_db *db, kid_db_info *out);
+void kid_db_destroy(kid_db *db);
+
+/* Hashtable::getHash (newkmer_10nx.cpp:204-233) for a batch of keys, on the GPU.
+ * probes (nullable) receives the number of cells each lookup read. */
+int kid_db_lookup(kid_db *db, const uint64_t *keys, uint64_t n, uint32_t *targets, uint32_t *probes);
+/* Tree1::msca (newkmer_10nx.cpp:118-144) for a batch of (x,y), on the GPU. */
+int kid_db_msca(kid_db *db, const int32_t *x, const int32_t *y, uint64_t n, int32_t *out);
+
+/* ---- per-sample state ----------------------------------------------------
+ * Replaces the per-sample reset in main (newkmer_10nx.cpp:1017-1019,1023).   */
+int kid_sample_begin(kid_db *db, kid_sample **out);
+int kid_sample_reset(kid_sample *s);
+void kid_sample_destroy(kid_sample *s);
+
+/* ---- classification (THE hot path) -----------------------------------------
+ * Replaces process_read (newkmer_10nx.cpp:452-617) for n_reads reads at once.
+ *   bases     ASCII read text, all reads concatenated (any bytes; only ACGTacgt,
+ *             and Uu with KID_FLAG_U_IS_T, extend a k-mer: :478-525)
+ *   offsets   n_reads+1 byte offsets into bases (read r = [offsets[r], offsets[r+1]))
+ *   start/stop  inclusive range inside each read, as computed by process_qual
+ *             (:714-760); pass NULL/NULL for whole reads (the FASTA callers, :851)
+ *   out_final_targ  nullable; receives process_read's return value per read
+ * Side effects on the sample: gcount[final_targ]++ per read (:613), and every
+ * k-mer hit with target > 1 marks its table cell as seen (:596-603).
+ * Reads are independent; results do not depend on batch boundaries.            */
+int kid_classify_batch(kid_sample *s, const uint8_t *bases, const uint64_t *offsets,
+                       const int32_t *start, const int32_t *stop, uint64_t n_reads,
+                       uint32_t *out_final_targ);
+/* Device-resident form, asynchronous on `stream` (a hipStream_t, NULL = default
+ * stream).  The allocation behind d_bases must extend at least 16 bytes past
+ * offsets[n_reads] (the kernel reads aligned 16-byte chunks).                     */
+int kid_classify_batch_device(kid_sample *s, const void *d_bases, const void *d_offsets,
+                              const void *d_start, const void *d_stop, uint64_t n_reads,
+                              void *d_out_final_targ, void *stream);
+/* Fixed-length reads laid out back to back (read r = bases[r*read_len, (r+1)*read_len)),
+ * whole reads, no offsets array: the layout of the synthetic roofline runs.      */
+int kid_classify_fixed_device(kid_sample *s, const void *d_bases, uint32_t read_len,
+                              uint64_t n_reads, void *d_out_final_targ, void *stream);
+
+/* process_qual (newkmer_10nx.cpp:714-760) for a batch: quals laid out like bases.
+ * keep[r] = 1 if the reference would call process_read (stop-start >= k).        */
+int kid_trim_batch(kid_db *db, const uint8_t *quals, const uint64_t *offsets, uint64_t n_reads,
+                   int32_t *start, int32_t *stop, uint8_t *keep);
+
+/* ---- results -----------------------------------------------------------------
+ * gcount[ntar], ucount[ntar] as written to <prefix>_result.txt (:1040-1043).
+ * Synchronises the sample's outstanding work first.                             */
+int kid_sample_end(kid_sample *s, int64_t *gcount, int64_t *ucount);
+/* {reads, k-mer lookups, table cells read, k-mer hits} so far (synchronises) */
+int kid_sample_stats(kid_sample *s, uint64_t out[4]);
+
+/* ---- multi-GPU merge helpers (reads sharded over ranks, DB replicated) ---------
+ * ucount is |distinct DB k-mers hit| and is not additive over shards: ranks
+ * exchange slices of the per-cell "seen" bitmap, OR them, and count their slice. */
+int kid_sample_seen_bytes(const kid_sample *s, uint64_t *nbytes);
+int kid_sample_seen_export(kid_sample *s, uint64_t byte_off, uint64_t nbytes, void *dst, int dst_on_device);
+int kid_sample_seen_or(kid_sample *s, uint64_t byte_off, uint64_t nbytes, const void *src, int src_on_device);
+int kid_sample_gcount(kid_sample *s, int64_t *gcount);
+/* ucount contribution of the table cells [slot_begin, slot_end) */
+int kid_sample_ucount_range(kid_sample *s, uint64_t slot_begin, uint64_t slot_end, int64_t *ucount);
+
+/* ---- synthetic workload generators (bench + tests; deterministic, seeded) ------
+ * DB key j = canonical(splitmix64(seed + j) mod 4^k); target of key j follows
+ * cum[] (cum[t] <= j < cum[t+1]).  Reads: see DESIGN.md "synthetic workload".    */
+int kid_synth_db_keys_host(uint64_t seed, int k, const uint64_t *cum, int32_t ntar,
+                           uint64_t j0, uint64_t n, uint64_t *keys, uint32_t *targets);
+int kid_synth_db_keys_device(uint64_t seed, int k, const uint64_t *cum_host, int32_t ntar,
+                             uint64_t j0, uint64_t n, void *d_keys, void *d_targets, int device);
+int kid_synth_reads_host(uint64_t db_seed, uint64_t read_seed, int k, const uint64_t *cum,
+                         const int32_t *parent, int32_t ntar, uint64_t r0, uint64_t n_reads,
+                         uint32_t read_len, uint8_t *bases);
+int kid_synth_reads_device(uint64_t db_seed, uint64_t read_seed, int k, const uint64_t *cum_host,
+                           const int32_t *parent_host, int32_t ntar, uint64_t r0, uint64_t n_reads,
+                           uint32_t read_len, void *d_bases, int device);
+
+/* random 16-byte gather micro-benchmark over the DB's own table: the measured
+ * ceiling the lookup kernel is priced against.  n_loads random cells are read,
+ * `inflight` (1,2,4,8) independent loads per lane; *ms_out = milliseconds per
+ * launch, *loads_out = loads one launch issued.                                   */
+int kid_bench_gather(kid_db *db, uint64_t n_loads, int inflight, int iters, float *ms_out, uint64_t *loads_out);
+
+/* device memory helpers so that a host language without a HIP binding can stage buffers */
+int kid_dev_alloc(int device, uint64_t nbytes, void **d_ptr);
+int kid_dev_free(int device, void *d_ptr);
+int kid_dev_upload(int device, void *d_dst, const void *src, uint64_t nbytes);
+int kid_dev_download(int device, void *dst, const void *d_src, uint64_t nbytes);
+int kid_dev_sync(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMER_ID_AMD_H */

@@ -1,0 +1,87 @@
+"""Build the in-tree native artefacts with hipcc (gfx950 only).
+
+`libkmer_id_amd.so` is a plain C-ABI shared library (include/kmer_id_amd.h); it is
+compiled in-tree so that it travels to the GPU box with the repository snapshot.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+LIB = os.path.join(HERE, "libkmer_id_amd.so")
+BIN_DIR = os.path.join(HERE, "bin")
+NK10 = os.path.join(BIN_DIR, "nk10")
+
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the MI355X library cannot be built")
+    return exe
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def lib_sources():
+    return [os.path.join(CSRC, f) for f in ("kid_api.hip", "kid_kernels.hip.h", "kid_common.h")] + [
+        os.path.join(ROOT, "include", "kmer_id_amd.h")]
+
+
+def build_library(force=False, verbose=False):
+    srcs = lib_sources()
+    if force or _newer(LIB, srcs):
+        cmd = [_hipcc()] + HIPCC_FLAGS + ["-shared", "-o", LIB, os.path.join(CSRC, "kid_api.hip")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def host_sources():
+    if not os.path.isdir(HOST):
+        return []
+    return sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith((".cpp", ".h")))
+
+
+def build_cli(force=False, verbose=False):
+    """nk10: the reference-compatible command line program (host C++ over the C ABI)."""
+    srcs = host_sources()
+    cpps = [s for s in srcs if s.endswith(".cpp")]
+    if not cpps:
+        return None
+    build_library(force=force, verbose=verbose)
+    os.makedirs(BIN_DIR, exist_ok=True)
+    if force or _newer(NK10, srcs + [LIB]):
+        cxx = shutil.which("g++") or "g++"
+        cmd = [cxx, "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", NK10] + cpps + [
+            "-L", HERE, "-lkmer_id_amd", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return NK10
+
+
+def build_oracle(verbose=False):
+    """The plain-C checker (test infrastructure) and, where the reference sources are
+    present (build container only), the compiled reference under oracle/_ref."""
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.check_call(["make", "-C", odir, "oracle"] + ([] if verbose else ["-s"]))
+    if os.path.exists("/root/reference/newkmer_10nx.cpp"):
+        subprocess.check_call(["make", "-C", odir, "ref"] + ([] if verbose else ["-s"]))
+    return os.path.join(odir, "libkmer_oracle.so")
+
+
+def build_all(force=False, verbose=False):
+    build_library(force=force, verbose=verbose)
+    build_cli(force=force, verbose=verbose)
+    build_oracle(verbose=verbose)

@@ -1,0 +1,857 @@
+// kid_api.hip -- C ABI (include/kmer_id_amd.h) over the gfx950 kernels.
+// Host side: handle bookkeeping, tree preparation, the reference-order host
+// table builder, launches.  No classification work is done on the CPU.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/kmer_id_amd.h"
+#include "kid_kernels.hip.h"
+
+static thread_local std::string g_last_error;
+
+static int kid_fail(int status, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return status;
+}
+
+#define KID_HIP(call)                                                                                              \
+    do {                                                                                                           \
+        hipError_t e_ = (call);                                                                                    \
+        if (e_ != hipSuccess)                                                                                      \
+            return kid_fail(e_ == hipErrorOutOfMemory ? KID_ERR_NOMEM : KID_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
+                            hipGetErrorString(e_), __FILE__, __LINE__);                                            \
+    } while (0)
+
+struct kid_db {
+    int device = 0;
+    int num_cu = 0;
+    KidDevDb d{};
+    uint4 *table = nullptr;
+    uint4 *rows = nullptr;
+    int32_t *parent = nullptr;
+    int32_t *depth = nullptr;
+    kid_db_info info{};
+};
+
+struct kid_sample {
+    kid_db *db = nullptr;
+    unsigned long long *gcount = nullptr; // [ntar]
+    unsigned long long *ucount = nullptr; // [ntar]
+    unsigned long long *stats = nullptr;  // [8]
+    uint32_t *seen = nullptr;
+    uint64_t seen_words = 0;
+    hipStream_t stream = nullptr;
+    // staging for the host-buffer entry point
+    uint8_t *st_bases = nullptr;
+    uint64_t st_bases_cap = 0;
+    uint64_t *st_offsets = nullptr;
+    int32_t *st_start = nullptr, *st_stop = nullptr;
+    uint32_t *st_out = nullptr;
+    uint64_t st_reads_cap = 0;
+};
+
+extern "C" const char *kid_strerror(int status)
+{
+    switch (status) {
+    case KID_OK: return "ok";
+    case KID_ERR_ARG: return "bad argument";
+    case KID_ERR_NOMEM: return "out of memory";
+    case KID_ERR_HIP: return "HIP runtime error";
+    case KID_ERR_TABLE_FULL: return "out of memory in table";
+    case KID_ERR_TREE: return "taxonomy parent[] is out of range or cyclic";
+    case KID_ERR_NO_DEVICE: return "no HIP device";
+    case KID_ERR_TARGET: return "target id outside [0, ntar)";
+    case KID_ERR_IO: return "I/O error";
+    case KID_ERR_FORMAT: return "malformed input";
+    case KID_ERR_STATE: return "call sequence error";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char *kid_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int kid_device_count(int *count)
+{
+    if (!count) return kid_fail(KID_ERR_ARG, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return kid_fail(KID_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return KID_OK;
+}
+
+static int kid_use_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return kid_fail(KID_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                        e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return kid_fail(KID_ERR_ARG, "device %d out of range [0,%d)", device, n);
+    KID_HIP(hipSetDevice(device));
+    return KID_OK;
+}
+
+static inline int kid_grid_for(uint64_t n, int block, int cap_blocks)
+{
+    uint64_t g = (n + (uint64_t)block - 1) / (uint64_t)block;
+    if (g < 1) g = 1;
+    if (g > (uint64_t)cap_blocks) g = (uint64_t)cap_blocks;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------- taxonomy preparation
+// effective parent = Tree1::get_parent (newkmer_10nx.cpp:146-152): nodes 0 and 1 answer root.
+static int kid_prepare_tree(const int32_t *parent, int32_t ntar, std::vector<int32_t> &par, std::vector<int32_t> &depth,
+                            int &max_depth)
+{
+    par.assign((size_t)ntar, 1);
+    depth.assign((size_t)ntar, -1);
+    for (int32_t i = 0; i < ntar; i++) {
+        int32_t p = (i != 1 && i > 0) ? parent[i] : 1;
+        if (p < 0 || p >= ntar) return kid_fail(KID_ERR_TREE, "parent[%d] = %d is outside [0,%d)", i, p, ntar);
+        par[(size_t)i] = p;
+    }
+    depth[1] = 0;
+    max_depth = 0;
+    std::vector<int32_t> stack;
+    for (int32_t i = 0; i < ntar; i++) {
+        if (depth[(size_t)i] >= 0) continue;
+        stack.clear();
+        int32_t z = i;
+        while (depth[(size_t)z] < 0) {
+            if ((int32_t)stack.size() > ntar) return kid_fail(KID_ERR_TREE, "cycle in parent[] reachable from node %d", i);
+            depth[(size_t)z] = -2; // on stack
+            stack.push_back(z);
+            z = par[(size_t)z];
+            if (depth[(size_t)z] == -2) return kid_fail(KID_ERR_TREE, "cycle in parent[] reachable from node %d", i);
+        }
+        int32_t d = depth[(size_t)z];
+        for (size_t j = stack.size(); j-- > 0;) depth[(size_t)stack[j]] = ++d;
+    }
+    for (int32_t i = 0; i < ntar; i++) max_depth = depth[(size_t)i] > max_depth ? depth[(size_t)i] : max_depth;
+    return KID_OK;
+}
+
+static void kid_make_rows(const std::vector<int32_t> &par, const std::vector<int32_t> &depth, std::vector<uint4> &rows)
+{
+    const size_t ntar = par.size();
+    rows.assign(ntar, make_uint4(0, 0, 0, 0));
+    for (size_t i = 0; i < ntar; i++) {
+        uint16_t e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int32_t d = depth[i];
+        e[0] = (uint16_t)d;
+        int32_t z = (int32_t)i;
+        while (d >= 1) {
+            if (d <= 7) e[d] = (uint16_t)z;
+            z = par[(size_t)z];
+            d--;
+        }
+        rows[i] = make_uint4((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
+                             (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16));
+    }
+}
+
+// ---------------------------------------------------------------- host table builder
+// Hashtable::add_kmer replayed in file order into 16-byte cells: the exact cell
+// geometry of the reference, needed when lookups are probe-capped (kmer_read_m3).
+static int kid_host_build(const uint64_t *keys, const uint32_t *targets, uint64_t n, int log2_slots, uint4 *cells,
+                          uint64_t *n_occupied)
+{
+    const uint64_t nslots = 1ULL << log2_slots, mask = nslots - 1;
+    uint64_t size = 0, occ = 0;
+    for (uint64_t e = 0; e < n; e++) {
+        const uint64_t key = keys[e], hash = kid_fmix64(key);
+        uint64_t reprobe = 0, i = 0;
+        for (;;) {
+            const uint64_t idx = (hash + reprobe) & mask;
+            reprobe += ++i;
+            if (cells[idx].z == 0) {
+                cells[idx].x = (uint32_t)key;
+                cells[idx].y = (uint32_t)(key >> 32);
+                cells[idx].z = targets[e];
+                cells[idx].w = (uint32_t)e + 1u;
+                if (targets[e] != 0) occ++;
+                if (++size > nslots - 32) return kid_fail(KID_ERR_TABLE_FULL, "out of memory in table");
+                break;
+            }
+        }
+    }
+    *n_occupied = occ;
+    return KID_OK;
+}
+
+static int kid_db_build_common(const uint64_t *h_keys, const uint32_t *h_targets, const void *d_keys_in,
+                               const void *d_targets_in, uint64_t n, const int32_t *parent, int32_t ntar, int k,
+                               int log2_slots, int max_probes, uint32_t flags, int device, kid_db **out)
+{
+    if (!out) return kid_fail(KID_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (!parent || ntar < 2) return kid_fail(KID_ERR_ARG, "parent is null or ntar < 2");
+    if (k < 1 || k > 31) return kid_fail(KID_ERR_ARG, "k = %d outside [1,31]", k);
+    if (log2_slots < 6 || log2_slots > 32) return kid_fail(KID_ERR_ARG, "log2_slots = %d outside [6,32]", log2_slots);
+    if (max_probes < 0) return kid_fail(KID_ERR_ARG, "max_probes < 0");
+    if (n > 0 && !((h_keys && h_targets) || (d_keys_in && d_targets_in))) return kid_fail(KID_ERR_ARG, "keys/targets null");
+    if (n >= 0xFFFFFFFFull) return kid_fail(KID_ERR_ARG, "more than 2^32-2 entries");
+    const uint64_t nslots = 1ULL << log2_slots;
+    if (n > nslots - 32) return kid_fail(KID_ERR_TABLE_FULL, "out of memory in table");
+    int rc = kid_use_device(device);
+    if (rc != KID_OK) return rc;
+
+    std::vector<int32_t> par, depth;
+    int max_depth = 0;
+    rc = kid_prepare_tree(parent, ntar, par, depth, max_depth);
+    if (rc != KID_OK) return rc;
+    if (h_targets)
+        for (uint64_t i = 0; i < n; i++)
+            if (h_targets[i] >= (uint32_t)ntar) return kid_fail(KID_ERR_TARGET, "targets[%llu] = %u >= ntar", (unsigned long long)i, h_targets[i]);
+
+    kid_db *db = new kid_db();
+    db->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) db->num_cu = prop.multiProcessorCount;
+    if (db->num_cu <= 0) db->num_cu = 256;
+
+#define KID_DB_HIP(call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            kid_db_destroy(db);                                                                  \
+            return kid_fail(e_ == hipErrorOutOfMemory ? KID_ERR_NOMEM : KID_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+        }                                                                                        \
+    } while (0)
+
+    const uint64_t table_bytes = nslots * sizeof(uint4);
+    KID_DB_HIP(hipMalloc(&db->table, table_bytes));
+    KID_DB_HIP(hipMalloc(&db->parent, sizeof(int32_t) * (size_t)ntar));
+    KID_DB_HIP(hipMalloc(&db->depth, sizeof(int32_t) * (size_t)ntar));
+    KID_DB_HIP(hipMemcpy(db->parent, par.data(), sizeof(int32_t) * (size_t)ntar, hipMemcpyHostToDevice));
+    KID_DB_HIP(hipMemcpy(db->depth, depth.data(), sizeof(int32_t) * (size_t)ntar, hipMemcpyHostToDevice));
+    const bool rows_ok = (max_depth <= 8 && ntar <= 65536);
+    if (rows_ok) {
+        std::vector<uint4> rows;
+        kid_make_rows(par, depth, rows);
+        KID_DB_HIP(hipMalloc(&db->rows, sizeof(uint4) * (size_t)ntar));
+        KID_DB_HIP(hipMemcpy(db->rows, rows.data(), sizeof(uint4) * (size_t)ntar, hipMemcpyHostToDevice));
+    }
+
+    uint64_t n_occupied = 0;
+    const bool host_build = (max_probes > 0) || (flags & KID_FLAG_HOST_BUILD);
+    if (host_build) {
+        std::vector<uint64_t> hk;
+        std::vector<uint32_t> ht;
+        if (!h_keys && n > 0) { // entries live on the device: fetch them
+            hk.resize(n); ht.resize(n);
+            KID_DB_HIP(hipMemcpy(hk.data(), d_keys_in, n * 8, hipMemcpyDeviceToHost));
+            KID_DB_HIP(hipMemcpy(ht.data(), d_targets_in, n * 4, hipMemcpyDeviceToHost));
+            h_keys = hk.data(); h_targets = ht.data();
+            for (uint64_t i = 0; i < n; i++)
+                if (h_targets[i] >= (uint32_t)ntar) { kid_db_destroy(db); return kid_fail(KID_ERR_TARGET, "targets[%llu] >= ntar", (unsigned long long)i); }
+        }
+        uint4 *cells = (uint4 *)calloc(nslots, sizeof(uint4));
+        if (!cells) { kid_db_destroy(db); return kid_fail(KID_ERR_NOMEM, "host table of %llu bytes", (unsigned long long)table_bytes); }
+        rc = kid_host_build(h_keys, h_targets, n, log2_slots, cells, &n_occupied);
+        if (rc != KID_OK) { free(cells); kid_db_destroy(db); return rc; }
+        hipError_t e = hipMemcpy(db->table, cells, table_bytes, hipMemcpyHostToDevice);
+        free(cells);
+        KID_DB_HIP(e);
+    } else {
+        KID_DB_HIP(hipMemset(db->table, 0, table_bytes));
+        if (n > 0) {
+            uint64_t *dk = nullptr;
+            uint32_t *dt = nullptr;
+            const uint64_t *dkc = (const uint64_t *)d_keys_in;
+            const uint32_t *dtc = (const uint32_t *)d_targets_in;
+            if (!dkc) {
+                KID_DB_HIP(hipMalloc(&dk, n * 8));
+                hipError_t e = hipMalloc(&dt, n * 4);
+                if (e != hipSuccess) { hipFree(dk); KID_DB_HIP(e); }
+                KID_DB_HIP(hipMemcpy(dk, h_keys, n * 8, hipMemcpyHostToDevice));
+                KID_DB_HIP(hipMemcpy(dt, h_targets, n * 4, hipMemcpyHostToDevice));
+                dkc = dk; dtc = dt;
+            }
+            unsigned long long *d_occ = nullptr;
+            KID_DB_HIP(hipMalloc(&d_occ, 16));
+            KID_DB_HIP(hipMemset(d_occ, 0, 16));
+            const int grid = kid_grid_for(n, 256, db->num_cu * 16);
+            hipLaunchKernelGGL(kid_build_insert_kernel, dim3(grid), dim3(256), 0, 0, db->table, (uint32_t)(nslots - 1), dkc,
+                               dtc, n, (uint32_t)ntar, d_occ);
+            hipLaunchKernelGGL(kid_build_firstwins_kernel, dim3(grid), dim3(256), 0, 0, db->table, (uint32_t)(nslots - 1),
+                               dkc, dtc, n);
+            hipError_t e = hipDeviceSynchronize();
+            unsigned long long occ[2] = {0, 0};
+            if (e == hipSuccess) e = hipMemcpy(occ, d_occ, 16, hipMemcpyDeviceToHost);
+            hipFree(d_occ);
+            if (dk) hipFree(dk);
+            if (dt) hipFree(dt);
+            KID_DB_HIP(e);
+            if (occ[1] != 0) { kid_db_destroy(db); return kid_fail(KID_ERR_TARGET, "%llu targets >= ntar", occ[1]); }
+            n_occupied = occ[0];
+        }
+    }
+#undef KID_DB_HIP
+
+    db->d.table = db->table;
+    db->d.nslots = nslots;
+    db->d.slot_mask = (uint32_t)(nslots - 1);
+    db->d.max_probes = (uint32_t)max_probes;
+    db->d.k = k;
+    db->d.u_is_t = (flags & KID_FLAG_U_IS_T) ? 1u : 0u;
+    db->d.rows = db->rows;
+    db->d.parent = db->parent;
+    db->d.depth = db->depth;
+    db->d.ntar = ntar;
+    db->info.ntar = ntar;
+    db->info.k = k;
+    db->info.log2_slots = log2_slots;
+    db->info.max_probes = max_probes;
+    db->info.flags = flags;
+    db->info.device = device;
+    db->info.tree_depth = max_depth;
+    db->info.host_built = host_build ? 1 : 0;
+    db->info.n_entries = n;
+    db->info.n_occupied = n_occupied;
+    db->info.table_bytes = table_bytes;
+    *out = db;
+    return KID_OK;
+}
+
+extern "C" int kid_db_build(const uint64_t *keys, const uint32_t *targets, uint64_t n, const int32_t *parent, int32_t ntar,
+                            int k, int log2_slots, int max_probes, uint32_t flags, int device, kid_db **out)
+{
+    return kid_db_build_common(keys, targets, nullptr, nullptr, n, parent, ntar, k, log2_slots, max_probes, flags, device, out);
+}
+
+extern "C" int kid_db_build_device(const void *d_keys, const void *d_targets, uint64_t n, const int32_t *parent,
+                                   int32_t ntar, int k, int log2_slots, int max_probes, uint32_t flags, int device,
+                                   kid_db **out)
+{
+    return kid_db_build_common(nullptr, nullptr, d_keys, d_targets, n, parent, ntar, k, log2_slots, max_probes, flags, device, out);
+}
+
+extern "C" int kid_db_get_info(const kid_db *db, kid_db_info *out)
+{
+    if (!db || !out) return kid_fail(KID_ERR_ARG, "null argument");
+    *out = db->info;
+    return KID_OK;
+}
+
+extern "C" void kid_db_destroy(kid_db *db)
+{
+    if (!db) return;
+    hipSetDevice(db->device);
+    if (db->table) hipFree(db->table);
+    if (db->rows) hipFree(db->rows);
+    if (db->parent) hipFree(db->parent);
+    if (db->depth) hipFree(db->depth);
+    delete db;
+}
+
+extern "C" int kid_db_lookup(kid_db *db, const uint64_t *keys, uint64_t n, uint32_t *targets, uint32_t *probes)
+{
+    if (!db || (n && (!keys || !targets))) return kid_fail(KID_ERR_ARG, "null argument");
+    int rc = kid_use_device(db->device);
+    if (rc != KID_OK) return rc;
+    if (n == 0) return KID_OK;
+    uint64_t *dk = nullptr;
+    uint32_t *dt = nullptr, *dp = nullptr;
+    KID_HIP(hipMalloc(&dk, n * 8));
+    KID_HIP(hipMalloc(&dt, n * 4));
+    if (probes) KID_HIP(hipMalloc(&dp, n * 4));
+    KID_HIP(hipMemcpy(dk, keys, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kid_lookup_kernel, dim3(kid_grid_for(n, 256, db->num_cu * 16)), dim3(256), 0, 0, db->d, dk, n, dt, dp);
+    KID_HIP(hipDeviceSynchronize());
+    KID_HIP(hipMemcpy(targets, dt, n * 4, hipMemcpyDeviceToHost));
+    if (probes) KID_HIP(hipMemcpy(probes, dp, n * 4, hipMemcpyDeviceToHost));
+    hipFree(dk); hipFree(dt); if (dp) hipFree(dp);
+    return KID_OK;
+}
+
+extern "C" int kid_db_msca(kid_db *db, const int32_t *x, const int32_t *y, uint64_t n, int32_t *out)
+{
+    if (!db || (n && (!x || !y || !out))) return kid_fail(KID_ERR_ARG, "null argument");
+    for (uint64_t i = 0; i < n; i++)
+        if (x[i] < 0 || x[i] >= db->info.ntar || y[i] < 0 || y[i] >= db->info.ntar)
+            return kid_fail(KID_ERR_TARGET, "pair %llu outside [0,ntar)", (unsigned long long)i);
+    int rc = kid_use_device(db->device);
+    if (rc != KID_OK) return rc;
+    if (n == 0) return KID_OK;
+    int32_t *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    KID_HIP(hipMalloc(&dx, n * 4));
+    KID_HIP(hipMalloc(&dy, n * 4));
+    KID_HIP(hipMalloc(&dout, n * 4));
+    KID_HIP(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+    KID_HIP(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kid_msca_kernel, dim3(kid_grid_for(n, 256, db->num_cu * 16)), dim3(256), 0, 0, db->d, dx, dy, n, dout);
+    KID_HIP(hipDeviceSynchronize());
+    KID_HIP(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    hipFree(dx); hipFree(dy); hipFree(dout);
+    return KID_OK;
+}
+
+// ---------------------------------------------------------------- sample
+extern "C" void kid_sample_destroy(kid_sample *s)
+{
+    if (!s) return;
+    if (s->db) hipSetDevice(s->db->device);
+    if (s->gcount) hipFree(s->gcount);
+    if (s->ucount) hipFree(s->ucount);
+    if (s->stats) hipFree(s->stats);
+    if (s->seen) hipFree(s->seen);
+    if (s->st_bases) hipFree(s->st_bases);
+    if (s->st_offsets) hipFree(s->st_offsets);
+    if (s->st_start) hipFree(s->st_start);
+    if (s->st_stop) hipFree(s->st_stop);
+    if (s->st_out) hipFree(s->st_out);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+}
+
+extern "C" int kid_sample_reset(kid_sample *s)
+{
+    if (!s) return kid_fail(KID_ERR_ARG, "null sample");
+    int rc = kid_use_device(s->db->device);
+    if (rc != KID_OK) return rc;
+    KID_HIP(hipDeviceSynchronize());
+    const size_t nt = (size_t)s->db->info.ntar;
+    KID_HIP(hipMemset(s->gcount, 0, nt * 8));
+    KID_HIP(hipMemset(s->ucount, 0, nt * 8));
+    KID_HIP(hipMemset(s->stats, 0, 64));
+    KID_HIP(hipMemset(s->seen, 0, s->seen_words * 4));
+    KID_HIP(hipDeviceSynchronize());
+    return KID_OK;
+}
+
+extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
+{
+    if (!db || !out) return kid_fail(KID_ERR_ARG, "null argument");
+    *out = nullptr;
+    int rc = kid_use_device(db->device);
+    if (rc != KID_OK) return rc;
+    kid_sample *s = new kid_sample();
+    s->db = db;
+    const size_t nt = (size_t)db->info.ntar;
+    s->seen_words = (db->d.nslots + 31) / 32;
+#define KID_S_HIP(call)                                                                                           \
+    do {                                                                                                          \
+        hipError_t e_ = (call);                                                                                   \
+        if (e_ != hipSuccess) {                                                                                   \
+            kid_sample_destroy(s);                                                                                \
+            return kid_fail(e_ == hipErrorOutOfMemory ? KID_ERR_NOMEM : KID_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+        }                                                                                                         \
+    } while (0)
+    KID_S_HIP(hipMalloc(&s->gcount, nt * 8));
+    KID_S_HIP(hipMalloc(&s->ucount, nt * 8));
+    KID_S_HIP(hipMalloc(&s->stats, 64));
+    KID_S_HIP(hipMalloc(&s->seen, s->seen_words * 4));
+    KID_S_HIP(hipStreamCreate(&s->stream));
+#undef KID_S_HIP
+    rc = kid_sample_reset(s);
+    if (rc != KID_OK) { kid_sample_destroy(s); return rc; }
+    *out = s;
+    return KID_OK;
+}
+
+// launch geometry: 512-thread workgroups (8 waves), persistent over the reads.
+// The gcount histogram lives in LDS when 4 workgroups per CU still fit.
+static int kid_launch_classify(kid_sample *s, const KidBatch &b, hipStream_t stream)
+{
+    kid_db *db = s->db;
+    if (b.n == 0) return KID_OK;
+    const int block = 512, wpb = block / 64;
+    const uint32_t ntar = (uint32_t)db->info.ntar;
+    const bool hist = (ntar * 4u <= 36u * 1024u);
+    const uint32_t hist_words = hist ? ((ntar + 3u) & ~3u) : 0u;
+    const size_t lds = ((size_t)hist_words + (size_t)wpb * KID_WAVE_LDS_WORDS) * 4;
+    const int grid = kid_grid_for(b.n, wpb, db->num_cu * 4);
+    KidSampleDev sd{s->gcount, s->seen, s->stats};
+    const bool rows = db->rows != nullptr;
+    if (rows && hist) hipLaunchKernelGGL((kid_classify_kernel<2, true, true>), dim3(grid), dim3(block), lds, stream, db->d, b, sd, hist_words);
+    else if (rows) hipLaunchKernelGGL((kid_classify_kernel<2, true, false>), dim3(grid), dim3(block), lds, stream, db->d, b, sd, hist_words);
+    else if (hist) hipLaunchKernelGGL((kid_classify_kernel<2, false, true>), dim3(grid), dim3(block), lds, stream, db->d, b, sd, hist_words);
+    else hipLaunchKernelGGL((kid_classify_kernel<2, false, false>), dim3(grid), dim3(block), lds, stream, db->d, b, sd, hist_words);
+    KID_HIP(hipGetLastError());
+    return KID_OK;
+}
+
+extern "C" int kid_classify_batch_device(kid_sample *s, const void *d_bases, const void *d_offsets, const void *d_start,
+                                         const void *d_stop, uint64_t n_reads, void *d_out_final_targ, void *stream)
+{
+    if (!s || (n_reads && (!d_bases || !d_offsets))) return kid_fail(KID_ERR_ARG, "null argument");
+    if (((uintptr_t)d_bases & 15u) != 0) return kid_fail(KID_ERR_ARG, "d_bases must be 16-byte aligned");
+    if ((d_start == nullptr) != (d_stop == nullptr)) return kid_fail(KID_ERR_ARG, "start and stop must both be given or both be null");
+    int rc = kid_use_device(s->db->device);
+    if (rc != KID_OK) return rc;
+    KidBatch b{};
+    b.bases = (const uint8_t *)d_bases;
+    b.offsets = (const uint64_t *)d_offsets;
+    b.start = (const int32_t *)d_start;
+    b.stop = (const int32_t *)d_stop;
+    b.out_final = (uint32_t *)d_out_final_targ;
+    b.n = n_reads;
+    b.fixed_len = 0;
+    return kid_launch_classify(s, b, (hipStream_t)stream);
+}
+
+extern "C" int kid_classify_fixed_device(kid_sample *s, const void *d_bases, uint32_t read_len, uint64_t n_reads,
+                                         void *d_out_final_targ, void *stream)
+{
+    if (!s || (n_reads && !d_bases)) return kid_fail(KID_ERR_ARG, "null argument");
+    if (((uintptr_t)d_bases & 15u) != 0) return kid_fail(KID_ERR_ARG, "d_bases must be 16-byte aligned");
+    if (read_len == 0 || read_len > 0x7FFFFFFFu) return kid_fail(KID_ERR_ARG, "read_len out of range");
+    int rc = kid_use_device(s->db->device);
+    if (rc != KID_OK) return rc;
+    KidBatch b{};
+    b.bases = (const uint8_t *)d_bases;
+    b.out_final = (uint32_t *)d_out_final_targ;
+    b.n = n_reads;
+    b.fixed_len = read_len;
+    return kid_launch_classify(s, b, (hipStream_t)stream);
+}
+
+extern "C" int kid_classify_batch(kid_sample *s, const uint8_t *bases, const uint64_t *offsets, const int32_t *start,
+                                  const int32_t *stop, uint64_t n_reads, uint32_t *out_final_targ)
+{
+    if (!s) return kid_fail(KID_ERR_ARG, "null sample");
+    if (n_reads == 0) return KID_OK;
+    if (!bases || !offsets) return kid_fail(KID_ERR_ARG, "null argument");
+    if ((start == nullptr) != (stop == nullptr)) return kid_fail(KID_ERR_ARG, "start and stop must both be given or both be null");
+    for (uint64_t r = 0; r < n_reads; r++) {
+        if (offsets[r + 1] < offsets[r]) return kid_fail(KID_ERR_ARG, "offsets not monotone at read %llu", (unsigned long long)r);
+        const uint64_t len = offsets[r + 1] - offsets[r];
+        if (len > 0x7FFFFFFFull) return kid_fail(KID_ERR_ARG, "read %llu longer than 2^31-1", (unsigned long long)r);
+        if (start && start[r] <= stop[r] && (start[r] < 0 || (uint64_t)stop[r] >= len))
+            return kid_fail(KID_ERR_ARG, "read %llu: [start,stop] = [%d,%d] outside the read of length %llu (string::at would throw)",
+                            (unsigned long long)r, start[r], stop[r], (unsigned long long)len);
+    }
+    int rc = kid_use_device(s->db->device);
+    if (rc != KID_OK) return rc;
+    const uint64_t base0 = offsets[0], nbytes = offsets[n_reads] - base0;
+    const uint64_t need = ((nbytes + 15) & ~15ull) + 32;
+    if (need > s->st_bases_cap) {
+        if (s->st_bases) hipFree(s->st_bases);
+        s->st_bases = nullptr; s->st_bases_cap = 0;
+        KID_HIP(hipMalloc(&s->st_bases, need));
+        s->st_bases_cap = need;
+    }
+    if (n_reads > s->st_reads_cap) {
+        if (s->st_offsets) hipFree(s->st_offsets);
+        if (s->st_start) hipFree(s->st_start);
+        if (s->st_stop) hipFree(s->st_stop);
+        if (s->st_out) hipFree(s->st_out);
+        s->st_offsets = nullptr; s->st_start = s->st_stop = nullptr; s->st_out = nullptr; s->st_reads_cap = 0;
+        KID_HIP(hipMalloc(&s->st_offsets, (n_reads + 1) * 8));
+        KID_HIP(hipMalloc(&s->st_start, n_reads * 4));
+        KID_HIP(hipMalloc(&s->st_stop, n_reads * 4));
+        KID_HIP(hipMalloc(&s->st_out, n_reads * 4));
+        s->st_reads_cap = n_reads;
+    }
+    hipStream_t st = s->stream;
+    std::vector<uint64_t> rel;
+    const uint64_t *off_src = offsets;
+    if (base0 != 0) {
+        rel.resize(n_reads + 1);
+        for (uint64_t r = 0; r <= n_reads; r++) rel[r] = offsets[r] - base0;
+        off_src = rel.data();
+    }
+    KID_HIP(hipMemsetAsync(s->st_bases + (nbytes & ~15ull), 0, need - (nbytes & ~15ull), st));
+    if (nbytes) KID_HIP(hipMemcpyAsync(s->st_bases, bases + base0, nbytes, hipMemcpyHostToDevice, st));
+    KID_HIP(hipMemcpyAsync(s->st_offsets, off_src, (n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+    if (start) {
+        KID_HIP(hipMemcpyAsync(s->st_start, start, n_reads * 4, hipMemcpyHostToDevice, st));
+        KID_HIP(hipMemcpyAsync(s->st_stop, stop, n_reads * 4, hipMemcpyHostToDevice, st));
+    }
+    KidBatch b{};
+    b.bases = s->st_bases;
+    b.offsets = s->st_offsets;
+    b.start = start ? s->st_start : nullptr;
+    b.stop = start ? s->st_stop : nullptr;
+    b.out_final = s->st_out;
+    b.n = n_reads;
+    rc = kid_launch_classify(s, b, st);
+    if (rc != KID_OK) return rc;
+    if (out_final_targ) KID_HIP(hipMemcpyAsync(out_final_targ, s->st_out, n_reads * 4, hipMemcpyDeviceToHost, st));
+    KID_HIP(hipStreamSynchronize(st));
+    return KID_OK;
+}
+
+extern "C" int kid_trim_batch(kid_db *db, const uint8_t *quals, const uint64_t *offsets, uint64_t n_reads, int32_t *start,
+                              int32_t *stop, uint8_t *keep)
+{
+    if (!db) return kid_fail(KID_ERR_ARG, "null db");
+    if (n_reads == 0) return KID_OK;
+    if (!quals || !offsets || !start || !stop || !keep) return kid_fail(KID_ERR_ARG, "null argument");
+    for (uint64_t r = 0; r < n_reads; r++)
+        if (offsets[r + 1] < offsets[r] || offsets[r + 1] - offsets[r] > 0x7FFFFFFFull)
+            return kid_fail(KID_ERR_ARG, "bad offsets at read %llu", (unsigned long long)r);
+    int rc = kid_use_device(db->device);
+    if (rc != KID_OK) return rc;
+    const uint64_t base0 = offsets[0], nbytes = offsets[n_reads] - base0;
+    uint8_t *dq = nullptr, *dkeep = nullptr;
+    uint64_t *doff = nullptr;
+    int32_t *ds = nullptr, *de = nullptr;
+    std::vector<uint64_t> rel(n_reads + 1);
+    for (uint64_t r = 0; r <= n_reads; r++) rel[r] = offsets[r] - base0;
+    KID_HIP(hipMalloc(&dq, nbytes + 16));
+    KID_HIP(hipMalloc(&doff, (n_reads + 1) * 8));
+    KID_HIP(hipMalloc(&ds, n_reads * 4));
+    KID_HIP(hipMalloc(&de, n_reads * 4));
+    KID_HIP(hipMalloc(&dkeep, n_reads));
+    if (nbytes) KID_HIP(hipMemcpy(dq, quals + base0, nbytes, hipMemcpyHostToDevice));
+    KID_HIP(hipMemcpy(doff, rel.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kid_trim_kernel, dim3(kid_grid_for(n_reads, 256, db->num_cu * 16)), dim3(256), 0, 0, dq, doff, n_reads,
+                       db->info.k, ds, de, dkeep);
+    KID_HIP(hipDeviceSynchronize());
+    KID_HIP(hipMemcpy(start, ds, n_reads * 4, hipMemcpyDeviceToHost));
+    KID_HIP(hipMemcpy(stop, de, n_reads * 4, hipMemcpyDeviceToHost));
+    KID_HIP(hipMemcpy(keep, dkeep, n_reads, hipMemcpyDeviceToHost));
+    hipFree(dq); hipFree(doff); hipFree(ds); hipFree(de); hipFree(dkeep);
+    return KID_OK;
+}
+
+// ---------------------------------------------------------------- results
+static int kid_check_errors(kid_sample *s)
+{
+    unsigned long long st[8];
+    KID_HIP(hipMemcpy(st, s->stats, 64, hipMemcpyDeviceToHost));
+    if (st[4] != 0)
+        return kid_fail(KID_ERR_ARG, "%llu reads had [start,stop] outside the read (string::at would throw)", st[4]);
+    return KID_OK;
+}
+
+extern "C" int kid_sample_gcount(kid_sample *s, int64_t *gcount)
+{
+    if (!s || !gcount) return kid_fail(KID_ERR_ARG, "null argument");
+    int rc = kid_use_device(s->db->device);
+    if (rc != KID_OK) return rc;
+    KID_HIP(hipDeviceSynchronize());
+    KID_HIP(hipMemcpy(gcount, s->gcount, (size_t)s->db->info.ntar * 8, hipMemcpyDeviceToHost));
+    return kid_check_errors(s);
+}
+
+extern "C" int kid_sample_ucount_range(kid_sample *s, uint64_t slot_begin, uint64_t slot_end, int64_t *ucount)
+{
+    if (!s || !ucount) return kid_fail(KID_ERR_ARG, "null argument");
+    if (slot_begin > slot_end || slot_end > s->db->d.nslots || (slot_begin & 31) || (slot_end & 31))
+        return kid_fail(KID_ERR_ARG, "slot range must be 32-aligned and inside the table");
+    int rc = kid_use_device(s->db->device);
+    if (rc != KID_OK) return rc;
+    KID_HIP(hipDeviceSynchronize());
+    const size_t nt = (size_t)s->db->info.ntar;
+    KID_HIP(hipMemset(s->ucount, 0, nt * 8));
+    const uint64_t w0 = slot_begin / 32, w1 = slot_end / 32;
+    if (w1 > w0) {
+        hipLaunchKernelGGL(kid_ucount_kernel, dim3(kid_grid_for(w1 - w0, 256, s->db->num_cu * 16)), dim3(256), 0, 0, s->seen, w0,
+                           w1, s->db->table, s->ucount);
+        KID_HIP(hipGetLastError());
+    }
+    KID_HIP(hipDeviceSynchronize());
+    KID_HIP(hipMemcpy(ucount, s->ucount, nt * 8, hipMemcpyDeviceToHost));
+    return KID_OK;
+}
+
+extern "C" int kid_sample_end(kid_sample *s, int64_t *gcount, int64_t *ucount)
+{
+    if (!s || !gcount || !ucount) return kid_fail(KID_ERR_ARG, "null argument");
+    int rc = kid_sample_gcount(s, gcount);
+    if (rc != KID_OK) return rc;
+    return kid_sample_ucount_range(s, 0, s->db->d.nslots, ucount);
+}
+
+extern "C" int kid_sample_stats(kid_sample *s, uint64_t out[4])
+{
+    if (!s || !out) return kid_fail(KID_ERR_ARG, "null argument");
+    int rc = kid_use_device(s->db->device);
+    if (rc != KID_OK) return rc;
+    KID_HIP(hipDeviceSynchronize());
+    unsigned long long st[8];
+    KID_HIP(hipMemcpy(st, s->stats, 64, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; i++) out[i] = st[i];
+    return KID_OK;
+}
+
+extern "C" int kid_sample_seen_bytes(const kid_sample *s, uint64_t *nbytes)
+{
+    if (!s || !nbytes) return kid_fail(KID_ERR_ARG, "null argument");
+    *nbytes = s->seen_words * 4;
+    return KID_OK;
+}
+
+extern "C" int kid_sample_seen_export(kid_sample *s, uint64_t byte_off, uint64_t nbytes, void *dst, int dst_on_device)
+{
+    if (!s || (nbytes && !dst)) return kid_fail(KID_ERR_ARG, "null argument");
+    if (byte_off + nbytes > s->seen_words * 4) return kid_fail(KID_ERR_ARG, "range outside the bitmap");
+    int rc = kid_use_device(s->db->device);
+    if (rc != KID_OK) return rc;
+    KID_HIP(hipDeviceSynchronize());
+    KID_HIP(hipMemcpy(dst, (const uint8_t *)s->seen + byte_off, nbytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    return KID_OK;
+}
+
+extern "C" int kid_sample_seen_or(kid_sample *s, uint64_t byte_off, uint64_t nbytes, const void *src, int src_on_device)
+{
+    if (!s || (nbytes && !src)) return kid_fail(KID_ERR_ARG, "null argument");
+    if ((byte_off & 3) || (nbytes & 3) || byte_off + nbytes > s->seen_words * 4)
+        return kid_fail(KID_ERR_ARG, "range must be 4-byte aligned and inside the bitmap");
+    int rc = kid_use_device(s->db->device);
+    if (rc != KID_OK) return rc;
+    if (nbytes == 0) return KID_OK;
+    const uint32_t *dsrc = (const uint32_t *)src;
+    uint32_t *tmp = nullptr;
+    if (!src_on_device) {
+        KID_HIP(hipMalloc(&tmp, nbytes));
+        KID_HIP(hipMemcpy(tmp, src, nbytes, hipMemcpyHostToDevice));
+        dsrc = tmp;
+    }
+    KID_HIP(hipDeviceSynchronize());
+    hipLaunchKernelGGL(kid_or_kernel, dim3(kid_grid_for(nbytes / 4, 256, s->db->num_cu * 16)), dim3(256), 0, 0,
+                       s->seen + byte_off / 4, dsrc, nbytes / 4);
+    KID_HIP(hipDeviceSynchronize());
+    if (tmp) hipFree(tmp);
+    return KID_OK;
+}
+
+// ---------------------------------------------------------------- synthetic workload
+extern "C" int kid_synth_db_keys_host(uint64_t seed, int k, const uint64_t *cum, int32_t ntar, uint64_t j0, uint64_t n,
+                                      uint64_t *keys, uint32_t *targets)
+{
+    if (!cum || !keys || !targets || ntar < 1 || k < 1 || k > 31) return kid_fail(KID_ERR_ARG, "bad argument");
+    for (uint64_t i = 0; i < n; i++) {
+        keys[i] = kid_synth_db_key(seed, k, j0 + i);
+        targets[i] = kid_synth_target_of(cum, ntar, j0 + i);
+    }
+    return KID_OK;
+}
+
+extern "C" int kid_synth_db_keys_device(uint64_t seed, int k, const uint64_t *cum_host, int32_t ntar, uint64_t j0, uint64_t n,
+                                        void *d_keys, void *d_targets, int device)
+{
+    if (!cum_host || !d_keys || !d_targets || ntar < 1 || k < 1 || k > 31) return kid_fail(KID_ERR_ARG, "bad argument");
+    int rc = kid_use_device(device);
+    if (rc != KID_OK) return rc;
+    uint64_t *dcum = nullptr;
+    KID_HIP(hipMalloc(&dcum, ((size_t)ntar + 1) * 8));
+    KID_HIP(hipMemcpy(dcum, cum_host, ((size_t)ntar + 1) * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kid_synth_keys_kernel, dim3(kid_grid_for(n, 256, 256 * 16)), dim3(256), 0, 0, seed, k, dcum, ntar, j0, n,
+                       (uint64_t *)d_keys, (uint32_t *)d_targets);
+    KID_HIP(hipDeviceSynchronize());
+    hipFree(dcum);
+    return KID_OK;
+}
+
+extern "C" int kid_synth_reads_host(uint64_t db_seed, uint64_t read_seed, int k, const uint64_t *cum, const int32_t *parent,
+                                    int32_t ntar, uint64_t r0, uint64_t n_reads, uint32_t read_len, uint8_t *bases)
+{
+    if (!cum || !parent || !bases || ntar < 2 || k < 1 || k > 31 || read_len == 0) return kid_fail(KID_ERR_ARG, "bad argument");
+    for (uint64_t i = 0; i < n_reads; i++)
+        kid_synth_read(db_seed, read_seed, k, cum, parent, ntar, r0 + i, read_len, bases + i * (uint64_t)read_len);
+    return KID_OK;
+}
+
+extern "C" int kid_synth_reads_device(uint64_t db_seed, uint64_t read_seed, int k, const uint64_t *cum_host,
+                                      const int32_t *parent_host, int32_t ntar, uint64_t r0, uint64_t n_reads,
+                                      uint32_t read_len, void *d_bases, int device)
+{
+    if (!cum_host || !parent_host || !d_bases || ntar < 2 || k < 1 || k > 31 || read_len == 0)
+        return kid_fail(KID_ERR_ARG, "bad argument");
+    int rc = kid_use_device(device);
+    if (rc != KID_OK) return rc;
+    uint64_t *dcum = nullptr;
+    int32_t *dpar = nullptr;
+    KID_HIP(hipMalloc(&dcum, ((size_t)ntar + 1) * 8));
+    KID_HIP(hipMalloc(&dpar, (size_t)ntar * 4));
+    KID_HIP(hipMemcpy(dcum, cum_host, ((size_t)ntar + 1) * 8, hipMemcpyHostToDevice));
+    KID_HIP(hipMemcpy(dpar, parent_host, (size_t)ntar * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kid_synth_reads_kernel, dim3(kid_grid_for(n_reads, 256, 256 * 16)), dim3(256), 0, 0, db_seed, read_seed, k,
+                       dcum, dpar, ntar, r0, n_reads, read_len, (uint8_t *)d_bases);
+    KID_HIP(hipDeviceSynchronize());
+    hipFree(dcum); hipFree(dpar);
+    return KID_OK;
+}
+
+extern "C" int kid_bench_gather(kid_db *db, uint64_t n_loads, int inflight, int iters, float *ms_out, uint64_t *loads_out)
+{
+    if (!db || !ms_out || !loads_out || iters < 1) return kid_fail(KID_ERR_ARG, "bad argument");
+    int rc = kid_use_device(db->device);
+    if (rc != KID_OK) return rc;
+    const int block = 256, grid = db->num_cu * 8;
+    const uint64_t lanes = (uint64_t)block * grid;
+    if (inflight != 1 && inflight != 2 && inflight != 4 && inflight != 8) return kid_fail(KID_ERR_ARG, "inflight must be 1,2,4 or 8");
+    uint64_t rounds = n_loads / (lanes * (uint64_t)inflight);
+    if (rounds < 1) rounds = 1;
+    uint32_t *sink = nullptr;
+    KID_HIP(hipMalloc(&sink, 16));
+    hipEvent_t e0, e1;
+    KID_HIP(hipEventCreate(&e0));
+    KID_HIP(hipEventCreate(&e1));
+    auto launch = [&]() {
+        switch (inflight) {
+        case 1: hipLaunchKernelGGL((kid_gather_kernel<1>), dim3(grid), dim3(block), 0, 0, db->table, db->d.slot_mask, rounds, sink); break;
+        case 2: hipLaunchKernelGGL((kid_gather_kernel<2>), dim3(grid), dim3(block), 0, 0, db->table, db->d.slot_mask, rounds, sink); break;
+        case 4: hipLaunchKernelGGL((kid_gather_kernel<4>), dim3(grid), dim3(block), 0, 0, db->table, db->d.slot_mask, rounds, sink); break;
+        default: hipLaunchKernelGGL((kid_gather_kernel<8>), dim3(grid), dim3(block), 0, 0, db->table, db->d.slot_mask, rounds, sink); break;
+        }
+    };
+    launch(); // warm-up
+    KID_HIP(hipDeviceSynchronize());
+    KID_HIP(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) launch();
+    KID_HIP(hipEventRecord(e1, 0));
+    KID_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    KID_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(sink);
+    *ms_out = ms / (float)iters;
+    *loads_out = rounds * lanes * (uint64_t)inflight; // loads actually issued per launch
+    return KID_OK;
+}
+
+// ---------------------------------------------------------------- device memory helpers
+extern "C" int kid_dev_alloc(int device, uint64_t nbytes, void **d_ptr)
+{
+    if (!d_ptr) return kid_fail(KID_ERR_ARG, "null argument");
+    int rc = kid_use_device(device);
+    if (rc != KID_OK) return rc;
+    KID_HIP(hipMalloc(d_ptr, nbytes ? nbytes : 16));
+    return KID_OK;
+}
+extern "C" int kid_dev_free(int device, void *d_ptr)
+{
+    int rc = kid_use_device(device);
+    if (rc != KID_OK) return rc;
+    if (d_ptr) KID_HIP(hipFree(d_ptr));
+    return KID_OK;
+}
+extern "C" int kid_dev_upload(int device, void *d_dst, const void *src, uint64_t nbytes)
+{
+    int rc = kid_use_device(device);
+    if (rc != KID_OK) return rc;
+    if (nbytes) KID_HIP(hipMemcpy(d_dst, src, nbytes, hipMemcpyHostToDevice));
+    return KID_OK;
+}
+extern "C" int kid_dev_download(int device, void *dst, const void *d_src, uint64_t nbytes)
+{
+    int rc = kid_use_device(device);
+    if (rc != KID_OK) return rc;
+    if (nbytes) KID_HIP(hipMemcpy(dst, d_src, nbytes, hipMemcpyDeviceToHost));
+    return KID_OK;
+}
+extern "C" int kid_dev_sync(int device)
+{
+    int rc = kid_use_device(device);
+    if (rc != KID_OK) return rc;
+    KID_HIP(hipDeviceSynchronize());
+    return KID_OK;
+}

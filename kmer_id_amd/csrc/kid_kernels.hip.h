@@ -1,0 +1,522 @@
+// kid_kernels.hip.h -- gfx950 (MI355X, CDNA4) kernels of the k-mer read classifier.
+//
+// All work here is integer / indexing work bounded by random reads of the hash
+// table in HBM; there is no MFMA-shaped computation on this path.
+//
+// Data layout in HBM
+//   table   uint4[2^log2_slots]   {key lo, key hi, target (0 = empty), insertion ordinal+1}
+//                                 one 16-byte cell = one global_load_dwordx4 per probe
+//   rows    uint4[ntar]           8 x u16 per taxonomy node: e0 = depth, e[d] = ancestor of
+//                                 the node at depth d (d = 1..7, the node itself at d = depth)
+//   parent  int32[ntar], depth int32[ntar]   (fallback for trees deeper than 8 levels)
+//   seen    u32[2^log2_slots / 32]  one bit per table cell, per sample (-> ucount)
+//   gcount  u64[ntar], stats u64[8] per sample
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kid_common.h"
+
+#define KID_WAVE 64
+#define KID_SEG_KMERS 960  // k-mers per read segment: 960 + 30 bases + 15 alignment slack <= 64 chunks of 16 B
+#define KID_WAVE_LDS_WORDS 100 // 66 packed-base words + 34 invalid-mask words per wave
+
+struct KidDevDb {
+    const uint4 *table;
+    uint64_t nslots;
+    uint32_t slot_mask;
+    uint32_t max_probes;
+    int k;
+    uint32_t u_is_t;
+    const uint4 *rows; // null when the tree does not fit the row encoding
+    const int32_t *parent;
+    const int32_t *depth;
+    int32_t ntar;
+};
+
+struct KidBatch {
+    const uint8_t *bases;
+    const uint64_t *offsets; // null: fixed_len layout
+    const int32_t *start;    // nullable
+    const int32_t *stop;     // nullable
+    uint32_t *out_final;     // nullable
+    uint64_t n;
+    uint32_t fixed_len;
+};
+
+struct KidSampleDev {
+    unsigned long long *gcount;
+    uint32_t *seen;
+    unsigned long long *stats; // [0] reads [1] lookups [2] probes [3] hits [4] argument errors
+};
+
+// ------------------------------------------------------------------ hash lookup
+// Hashtable::getHash, newkmer_10nx.cpp:204-233 (+ probe cap kmer_read_m3.cpp:232)
+__device__ __forceinline__ uint32_t kid_dev_lookup(const KidDevDb &db, uint64_t key, uint32_t &slot, uint32_t &nprobe)
+{
+    const uint64_t hash = kid_fmix64(key);
+    uint64_t reprobe = 0;
+    uint32_t i = 0, res = 0;
+    slot = 0;
+    do {
+        const uint32_t idx = ((uint32_t)hash + (uint32_t)reprobe) & db.slot_mask;
+        reprobe += ++i;
+        const uint4 c = db.table[idx];
+        if (c.z == 0) break;
+        if (c.x == (uint32_t)key && c.y == (uint32_t)(key >> 32)) { res = c.z; slot = idx; break; }
+    } while (reprobe < db.nslots && (db.max_probes == 0 || i < db.max_probes));
+    nprobe = i;
+    return res;
+}
+
+// ------------------------------------------------------------------ taxonomy
+// Tree1::msca, newkmer_10nx.cpp:118-144, on the ancestor-row encoding.
+// Let L = deepest common node of the two root paths.  The reference returns x
+// when y lies on x's root path (L == y), y when x lies on y's (L == x), else L.
+__device__ __forceinline__ uint32_t kid_row_entry(const uint4 &r, uint32_t d)
+{
+    const uint32_t w = d < 2 ? r.x : d < 4 ? r.y : d < 6 ? r.z : r.w;
+    return (d & 1) ? (w >> 16) : (w & 0xFFFFu);
+}
+
+__device__ __forceinline__ uint32_t kid_msca_rows(uint32_t x, const uint4 &rx, uint32_t y, const uint4 &ry, uint4 &rout)
+{
+    const uint32_t dx = rx.x & 0xFFFFu, dy = ry.x & 0xFFFFu;
+    const uint64_t lo = ((uint64_t)(rx.y ^ ry.y) << 32) | ((rx.x ^ ry.x) & 0xFFFF0000u);
+    const uint64_t hi = ((uint64_t)(rx.w ^ ry.w) << 32) | (rx.z ^ ry.z);
+    uint32_t f = lo ? (uint32_t)(__builtin_ctzll(lo) >> 4) : hi ? 4u + (uint32_t)(__builtin_ctzll(hi) >> 4) : 8u;
+    uint32_t c = f - 1; // entries 1..f-1 agree
+    c = c < dx ? c : dx;
+    c = c < dy ? c : dy;
+    if (c == 7 && dx == 8 && dy == 8 && x == y) c = 8; // depth-8 nodes are not stored in their own row
+    if (c == dy) { rout = rx; return x; }
+    if (c == dx) { rout = ry; return y; }
+    rout = rx;
+    rout.x = (rx.x & 0xFFFF0000u) | c;
+    return c == 0 ? 1u : kid_row_entry(rx, c);
+}
+
+// same function by climbing parent[]/depth[] (any tree shape)
+__device__ __forceinline__ uint32_t kid_msca_climb(const KidDevDb &db, uint32_t x, uint32_t y)
+{
+    uint32_t a = x, b = y;
+    int32_t da = db.depth[a], dd = db.depth[b];
+    while (da > dd) { a = (uint32_t)db.parent[a]; da--; }
+    while (dd > da) { b = (uint32_t)db.parent[b]; dd--; }
+    while (a != b) { a = (uint32_t)db.parent[a]; b = (uint32_t)db.parent[b]; }
+    if (a == y) return x;
+    if (a == x) return y;
+    return a;
+}
+
+// ------------------------------------------------------------------ base packing
+// 16 ASCII bases -> 32 bits of 2-bit codes (first base in the top bits) plus a
+// 16-bit mask of bytes that are not ACGTacgt (those reset the reference's
+// rolling window, newkmer_10nx.cpp:520-524).  4 bytes at a time, no per-byte branches.
+__device__ __forceinline__ void kid_pack16(const uint4 v, const uint32_t u_is_t, uint32_t &codes, uint32_t &inv)
+{
+    const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+    codes = 0;
+    inv = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t x = in[q];
+        const uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u; // A,C,G,T -> 0,1,2,3 in every byte
+        codes = (codes << 8) | ((c * 0x40100401u) >> 24);       // byte0 -> bits 7:6 ... byte3 -> bits 1:0
+        // rebuild the upper-case letter each code stands for and compare
+        const uint32_t c0 = c & 0x01010101u, c1 = (c >> 1) & 0x01010101u, t = c0 & c1;
+        const uint32_t expect = 0x40404040u | (0x01010101u ^ t) | ((c0 ^ c1) << 1) | (c1 << 2) | (t << 4);
+        uint32_t diff = (x & 0xDFDFDFDFu) ^ expect;
+        if (u_is_t) diff &= ~t; // 'U' = 'T' ^ 1 and decodes to code 3
+        const uint32_t nz = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u;
+        inv |= ((((nz >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * q);
+    }
+}
+
+// ------------------------------------------------------------------ classify
+// One wavefront per read.  Per segment of <= 960 k-mers:
+//   1. every lane loads one aligned 16-byte chunk of the read (coalesced) and
+//      packs it to 2 bits/base into the wave's private LDS strip;
+//   2. lane i extracts the k-mer window starting at base i from LDS with two
+//      shifts (no serial rolling), derives the reverse complement with a bit
+//      reversal, takes min(), hashes and probes the table in HBM -- U windows per
+//      lane in flight at once;
+//   3. hits are folded with msca in read-position order (the fold is not
+//      associative: newkmer_10nx.cpp:588-595) on wave-uniform registers;
+//   4. hit cells are marked in the sample's seen-bitmap (ucount, :596-603).
+// gcount is accumulated in an LDS histogram per workgroup and flushed once.
+template <int U, bool ROWS, bool HIST>
+__global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db, const KidBatch b, const KidSampleDev s,
+                                                            const uint32_t hist_words)
+{
+    extern __shared__ uint32_t kid_smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform
+    const uint32_t wpb = blockDim.x >> 6;
+    uint32_t *hist = kid_smem;
+    uint32_t *W = kid_smem + hist_words + wib * KID_WAVE_LDS_WORDS; // 66 words
+    uint32_t *IM = W + 66;                                          // 34 words
+    uint16_t *IM16 = reinterpret_cast<uint16_t *>(IM);
+
+    if (HIST) {
+        for (uint32_t i = threadIdx.x; i < hist_words; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+    }
+
+    const int k = db.k;
+    const uint64_t gw = (uint64_t)blockIdx.x * wpb + wib;
+    const uint64_t nw = (uint64_t)gridDim.x * wpb;
+    uint64_t n_lookups = 0, n_probes = 0; // per lane
+    uint32_t n_hits = 0, n_reads = 0, n_err = 0; // lane 0 / uniform
+    uint32_t pend_t = 0, pend_n = 0;             // !HIST: run-length buffer in front of the global gcount atomics
+
+    for (uint64_t r = gw; r < b.n; r += nw) {
+        uint64_t off;
+        int64_t rl;
+        if (b.offsets) {
+            off = b.offsets[r];
+            rl = (int64_t)(b.offsets[r + 1] - off);
+        } else {
+            off = r * (uint64_t)b.fixed_len;
+            rl = b.fixed_len;
+        }
+        int64_t s0 = b.start ? (int64_t)b.start[r] : 0;
+        int64_t e0 = b.stop ? (int64_t)b.stop[r] : rl - 1;
+        if (s0 < 0 || e0 >= rl) { // the reference would throw from string::at(); never read out of bounds here
+            n_err++;
+            if (s0 < 0) s0 = 0;
+            if (e0 >= rl) e0 = rl - 1;
+        }
+        off = __builtin_amdgcn_readfirstlane((uint32_t)off) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(off >> 32)) << 32);
+        const int32_t s0u = __builtin_amdgcn_readfirstlane((int32_t)s0);
+        const int64_t nk = (int64_t)__builtin_amdgcn_readfirstlane((int32_t)(e0 - s0 + 1 - (k - 1)));
+
+        uint32_t final_t = 0;
+        uint4 frow = make_uint4(0, 0, 0, 0);
+
+        for (int64_t seg = 0; seg < nk; seg += KID_SEG_KMERS) {
+            const uint32_t segk = (uint32_t)((nk - seg) < KID_SEG_KMERS ? (nk - seg) : KID_SEG_KMERS);
+            const uint64_t b0 = off + (uint64_t)s0u + (uint64_t)seg; // first base of the segment
+            const uint32_t nb = segk + (uint32_t)k - 1;
+            const uint64_t a0 = b0 & ~15ull;
+            const uint32_t sh = (uint32_t)(b0 & 15ull);
+            const uint32_t nchunks = (sh + nb + 15u) >> 4; // <= 64
+
+            // ---- 1. pack
+            {
+                uint32_t codes = 0, inv = 0;
+                if (lane < nchunks) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(b.bases + a0 + 16ull * lane);
+                    kid_pack16(v, db.u_is_t, codes, inv);
+                }
+                W[lane] = codes;
+                IM16[lane] = (uint16_t)inv;
+                if (lane < 2) { W[64 + lane] = 0; IM[32 + lane] = 0; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // ---- 2..4 per group of U*64 windows
+            for (uint32_t t0 = 0; t0 < segk; t0 += U * 64u) {
+                uint64_t key[U];
+                uint32_t hlo[U];
+                bool act[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t i = t0 + (uint32_t)u * 64u + lane;
+                    const uint32_t p = sh + (i < segk ? i : 0u);
+                    const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
+                    const uint64_t A = ((uint64_t)W[w0] << 32) | W[w0 + 1];
+                    const uint64_t B = W[w0 + 2];
+                    const uint64_t x = (A << o2) | ((B << o2) >> 32);
+                    const uint64_t keyF = x >> (64 - 2 * k);
+                    const uint64_t im = (((uint64_t)IM[(p >> 5) + 1] << 32) | IM[p >> 5]) >> (p & 31u);
+                    const bool valid = (i < segk) && ((im & ((1ull << k) - 1ull)) == 0);
+                    key[u] = kid_canonical(keyF, k);
+                    hlo[u] = (uint32_t)kid_fmix64(key[u]);
+                    act[u] = valid;
+                    n_lookups += valid ? 1u : 0u;
+                }
+                uint32_t tgt[U], slot[U], step[U];
+                uint64_t rp[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) { tgt[u] = 0; slot[u] = 0; step[u] = 0; rp[u] = 0; }
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < U; u++) any |= act[u];
+                while (any) {
+                    uint4 c[U];
+                    uint32_t idx[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        idx[u] = (hlo[u] + (uint32_t)rp[u]) & db.slot_mask;
+                        c[u] = make_uint4(0, 0, 0, 0);
+                        if (act[u]) c[u] = db.table[idx[u]];
+                    }
+                    any = false;
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        if (act[u]) {
+                            step[u]++;
+                            rp[u] += step[u];
+                            if (c[u].z == 0) act[u] = false;
+                            else if (c[u].x == (uint32_t)key[u] && c[u].y == (uint32_t)(key[u] >> 32)) {
+                                tgt[u] = c[u].z; slot[u] = idx[u]; act[u] = false;
+                            } else if (!(rp[u] < db.nslots) || (db.max_probes != 0 && step[u] >= db.max_probes)) act[u] = false;
+                        }
+                        any |= act[u];
+                    }
+                }
+                uint4 row[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    n_probes += step[u];
+                    row[u] = make_uint4(0, 0, 0, 0);
+                    if (tgt[u] > 0) {
+                        if (ROWS) row[u] = db.rows[tgt[u]];
+                        if (tgt[u] > 1) atomicOr(&s.seen[slot[u] >> 5], 1u << (slot[u] & 31u));
+                    }
+                }
+                // ---- 3. ordered fold over the hits (wave-uniform)
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    uint64_t m = __ballot(tgt[u] > 0);
+                    n_hits += (uint32_t)__popcll(m);
+                    while (m) {
+                        const int j = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)tgt[u], j);
+                        if (x == final_t) continue; // msca(x,x) = x
+                        uint4 rx = make_uint4(0, 0, 0, 0);
+                        if (ROWS) {
+                            rx.x = (uint32_t)__builtin_amdgcn_readlane((int)row[u].x, j);
+                            rx.y = (uint32_t)__builtin_amdgcn_readlane((int)row[u].y, j);
+                            rx.z = (uint32_t)__builtin_amdgcn_readlane((int)row[u].z, j);
+                            rx.w = (uint32_t)__builtin_amdgcn_readlane((int)row[u].w, j);
+                        }
+                        if (final_t == 0) { final_t = x; frow = rx; continue; } // :592-595
+                        if (ROWS) {
+                            uint4 ro;
+                            final_t = kid_msca_rows(x, rx, final_t, frow, ro); // :588-591
+                            frow = ro;
+                        } else {
+                            final_t = kid_msca_climb(db, x, final_t);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier(); // strip is rewritten by the next segment / read
+        }
+
+        n_reads++;
+        if (HIST) {
+            if (lane == 0) atomicAdd(&hist[final_t], 1u);
+        } else if (final_t == pend_t) {
+            pend_n++;
+        } else {
+            if (pend_n && lane == 0) atomicAdd(&s.gcount[pend_t], (unsigned long long)pend_n);
+            pend_t = final_t;
+            pend_n = 1;
+        }
+        if (lane == 0 && b.out_final) b.out_final[r] = final_t;
+    }
+    if (!HIST && pend_n && lane == 0) atomicAdd(&s.gcount[pend_t], (unsigned long long)pend_n);
+
+    // ---- flush
+    if (HIST) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < hist_words; i += blockDim.x) {
+            const uint32_t v = hist[i];
+            if (v) atomicAdd(&s.gcount[i], (unsigned long long)v);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        n_lookups += __shfl_xor(n_lookups, o);
+        n_probes += __shfl_xor(n_probes, o);
+    }
+    if (lane == 0) {
+        if (n_reads) atomicAdd(&s.stats[0], (unsigned long long)n_reads);
+        if (n_lookups) atomicAdd(&s.stats[1], (unsigned long long)n_lookups);
+        if (n_probes) atomicAdd(&s.stats[2], (unsigned long long)n_probes);
+        if (n_hits) atomicAdd(&s.stats[3], (unsigned long long)n_hits);
+        if (n_err) atomicAdd(&s.stats[4], (unsigned long long)n_err);
+    }
+}
+
+// ------------------------------------------------------------------ unit probes (parity tests)
+__global__ void kid_lookup_kernel(const KidDevDb db, const uint64_t *keys, uint64_t n, uint32_t *targets, uint32_t *probes)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t slot, np;
+        targets[i] = kid_dev_lookup(db, keys[i], slot, np);
+        if (probes) probes[i] = np;
+    }
+}
+
+__global__ void kid_msca_kernel(const KidDevDb db, const int32_t *x, const int32_t *y, uint64_t n, int32_t *out)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t a = (uint32_t)x[i], c = (uint32_t)y[i];
+        uint32_t r;
+        if (db.rows) {
+            uint4 ro;
+            r = kid_msca_rows(a, db.rows[a], c, db.rows[c], ro);
+        } else {
+            r = kid_msca_climb(db, a, c);
+        }
+        out[i] = (int32_t)r;
+    }
+}
+
+// process_qual, newkmer_10nx.cpp:714-760: one read per thread (sequential scan by nature)
+__global__ void kid_trim_kernel(const uint8_t *quals, const uint64_t *offsets, uint64_t n, int k,
+                                int32_t *start_out, int32_t *stop_out, uint8_t *keep)
+{
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+        const signed char *q = reinterpret_cast<const signed char *>(quals + offsets[r]);
+        const int len = (int)(offsets[r + 1] - offsets[r]);
+        int start = 0, stop = len - 1;
+        if (len <= 0) { start_out[r] = 0; stop_out[r] = -1; keep[r] = 0; continue; }
+        while (q[start] < 49 && start < stop) start++;
+        while (q[stop] < 49 && stop > start) stop--;
+        if (start < stop - 4) {
+            int w = 0;
+            for (int i = 0; i < 4; i++) w += q[start + i] - 32;
+            while (w < 68 && start < stop - 4) { w += q[start + 4] - q[start]; start++; }
+        }
+        if (start < stop - 4) {
+            int w = 0;
+            for (int i = 0; i < 4; i++) w += q[stop - i] - 32;
+            while (w < 68 && start < stop - 4) { w += q[stop - 4] - q[stop]; stop--; }
+        }
+        start_out[r] = start;
+        stop_out[r] = stop;
+        keep[r] = (stop - start >= k) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------ table build on the GPU
+// Pass 1: every entry claims the first free cell on its probe path (same path
+// as Hashtable::add_kmer, newkmer_10nx.cpp:235-263) with a CAS on the ordinal
+// word.  Like the reference there is no key comparison: duplicates take
+// separate cells.  Entries with target 0 are skipped: in the reference they
+// leave their cell "empty" (value == 0), i.e. invisible to every lookup.
+__global__ void kid_build_insert_kernel(uint4 *table, uint32_t slot_mask, const uint64_t *keys, const uint32_t *targets,
+                                        uint64_t n, uint32_t ntar, unsigned long long *n_occupied)
+{
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t t = targets[e];
+        if (t == 0) continue;
+        if (t >= ntar) { atomicAdd(n_occupied + 1, 1ull); continue; } // reported as KID_ERR_TARGET
+        const uint64_t key = keys[e];
+        const uint32_t h = (uint32_t)kid_fmix64(key);
+        uint32_t rp = 0, i = 0;
+        for (;;) {
+            const uint32_t idx = (h + rp) & slot_mask;
+            rp += ++i;
+            uint32_t *ordp = reinterpret_cast<uint32_t *>(table + idx) + 3;
+            if (atomicCAS(ordp, 0u, (uint32_t)e + 1u) == 0u) {
+                uint32_t *c = reinterpret_cast<uint32_t *>(table + idx);
+                c[0] = (uint32_t)key;
+                c[1] = (uint32_t)(key >> 32);
+                c[2] = t;
+                atomicAdd(n_occupied, 1ull);
+                break;
+            }
+        }
+    }
+}
+
+// Pass 2: the reference's lookup returns the FIRST-inserted copy of a key
+// (earlier inserts sit earlier on the path).  Pass 1 placed duplicate copies
+// in arbitrary order, so every entry walks its path to the end of the chain,
+// finds the smallest ordinal among the cells holding its key and writes that
+// entry's target into the first such cell -- the only one a lookup can reach.
+// Key and ordinal words are immutable during this pass; only target words of
+// "first" cells are written, and all writers of one cell write the same value.
+__global__ void kid_build_firstwins_kernel(uint4 *table, uint32_t slot_mask, const uint64_t *keys, const uint32_t *targets,
+                                           uint64_t n)
+{
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+        if (targets[e] == 0 || table == nullptr) continue;
+        const uint64_t key = keys[e];
+        const uint32_t h = (uint32_t)kid_fmix64(key);
+        uint32_t rp = 0, i = 0, first_idx = 0, min_ord = 0, copies = 0;
+        for (;;) {
+            const uint32_t idx = (h + rp) & slot_mask;
+            rp += ++i;
+            const uint32_t *c = reinterpret_cast<const uint32_t *>(table + idx);
+            const uint32_t ord = c[3];
+            if (ord == 0) break;
+            if (c[0] == (uint32_t)key && c[1] == (uint32_t)(key >> 32)) {
+                if (copies == 0) { first_idx = idx; min_ord = ord; }
+                else if (ord < min_ord) min_ord = ord;
+                copies++;
+            }
+        }
+        if (copies > 1) reinterpret_cast<uint32_t *>(table + first_idx)[2] = targets[min_ord - 1];
+    }
+}
+
+// ------------------------------------------------------------------ ucount from the seen-bitmap
+// ucount[t] = number of distinct DB k-mers of target t seen in the sample
+// (newkmer_10nx.cpp:596-603), counted over the cells [w_begin*32, w_end*32)
+__global__ void kid_ucount_kernel(const uint32_t *seen, uint64_t w_begin, uint64_t w_end, const uint4 *table,
+                                  unsigned long long *ucount)
+{
+    for (uint64_t w = w_begin + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < w_end; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t bits = seen[w];
+        while (bits) {
+            const uint32_t bpos = (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1;
+            const uint32_t t = table[w * 32ull + bpos].z;
+            atomicAdd(&ucount[t], 1ull);
+        }
+    }
+}
+
+__global__ void kid_or_kernel(uint32_t *dst, const uint32_t *src, uint64_t nwords)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * blockDim.x)
+        dst[i] |= src[i];
+}
+
+// ------------------------------------------------------------------ synthetic data
+__global__ void kid_synth_keys_kernel(uint64_t seed, int k, const uint64_t *cum, int32_t ntar, uint64_t j0, uint64_t n,
+                                      uint64_t *keys, uint32_t *targets)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        keys[i] = kid_synth_db_key(seed, k, j0 + i);
+        targets[i] = kid_synth_target_of(cum, ntar, j0 + i);
+    }
+}
+
+__global__ void kid_synth_reads_kernel(uint64_t db_seed, uint64_t read_seed, int k, const uint64_t *cum,
+                                       const int32_t *parent, int32_t ntar, uint64_t r0, uint64_t n, uint32_t len,
+                                       uint8_t *bases)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        kid_synth_read(db_seed, read_seed, k, cum, parent, ntar, r0 + i, len, bases + i * (uint64_t)len);
+}
+
+// ------------------------------------------------------------------ random-gather ceiling
+// INF independent 16-byte loads per lane per round from uniformly random cells
+template <int INF>
+__global__ __launch_bounds__(256) void kid_gather_kernel(const uint4 *table, uint32_t slot_mask, uint64_t rounds, uint32_t *sink)
+{
+    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    uint32_t acc = 0;
+    uint64_t ctr = tid * 0x9E3779B97F4A7C15ULL;
+    for (uint64_t r = 0; r < rounds; r++) {
+        uint4 c[INF];
+#pragma unroll
+        for (int u = 0; u < INF; u++) {
+            ctr += 0xD1B54A32D192ED03ULL;
+            c[u] = table[(uint32_t)kid_fmix64(ctr) & slot_mask];
+        }
+#pragma unroll
+        for (int u = 0; u < INF; u++) acc ^= c[u].x ^ c[u].z;
+    }
+    if (acc == 0x12345678u) sink[0] = acc; // never true in practice; keeps the loads alive
+}

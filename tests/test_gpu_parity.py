@@ -1,0 +1,426 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and with the golden
+vectors of the compiled reference.  Bit-exact: everything here is integer work."""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import kmer_id_amd
+from kmer_id_amd import KID_FLAG_HOST_BUILD, KID_FLAG_U_IS_T, KmerDB, synth
+from helpers import K, concat_reads, ob, oracle_db, parse_probes_text, small_db, unpack_strings
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kat_entries(kat):
+    text = gzip.decompress(bytes(kat["probes_gz"]))
+    keys, targets = parse_probes_text(text)
+    parent, _ = synth.load_taxonomy("bact10")
+    return parent, keys, targets
+
+
+@pytest.fixture(scope="module", params=["gpu_build", "host_build"])
+def kat_db(request, kat, kat_entries):
+    parent, keys, targets = kat_entries
+    flags = KID_FLAG_HOST_BUILD if request.param == "host_build" else 0
+    db = KmerDB(keys, targets, parent, k=K, log2_slots=int(kat["log2_slots"]), flags=flags)
+    assert db.info.host_built == (1 if flags else 0)
+    yield db
+    db.close()
+
+
+def test_gethash_golden(kat, kat_db):
+    got = kat_db.lookup(kat["lookup_in"]).astype(np.int64)
+    assert np.array_equal(got, kat["lookup_out"])
+
+
+def test_host_built_table_has_reference_geometry(kat, kat_entries):
+    """same probe counts as the oracle's table => same cell for every entry"""
+    parent, keys, targets = kat_entries
+    db = KmerDB(keys, targets, parent, k=K, log2_slots=12, flags=KID_FLAG_HOST_BUILD)
+    odb = oracle_db(parent, keys, targets, 12)
+    t, p = db.lookup(kat["lookup_in"], with_probes=True)
+    et, ep = odb.get(kat["lookup_in"], with_probes=True)
+    assert np.array_equal(t, et) and np.array_equal(p, ep)
+    assert db.info.n_occupied == int((targets != 0).sum()) - 1  # the (z0,0) cell is re-used by (z0,5)
+
+
+def test_msca_golden_pairs(kat, kat_db):
+    got = kat_db.msca(kat["msca_x"], kat["msca_y"])
+    assert np.array_equal(got, kat["msca_out"])
+
+
+def _mix(k):
+    k = k.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        k ^= k >> np.uint64(30); k *= np.uint64(0xbf58476d1ce4e5b9)
+        k ^= k >> np.uint64(27); k *= np.uint64(0x94d049bb133111eb)
+        k ^= k >> np.uint64(31)
+    return k
+
+
+def test_msca_all_pairs_checksum(kat, kat_db):
+    ntar = int(kat["msca_all_ntar"])
+    ys = np.arange(1, ntar, dtype=np.int32)
+    total = np.uint64(0)
+    rows = 256
+    with np.errstate(over="ignore"):
+        for x0 in range(1, ntar, rows):
+            xs = np.arange(x0, min(ntar, x0 + rows), dtype=np.int32)
+            X = np.repeat(xs, ys.size)
+            Y = np.tile(ys, xs.size)
+            m = kat_db.msca(X, Y).astype(np.uint64)
+            w = _mix(X.astype(np.uint64) * np.uint64(ntar) + Y.astype(np.uint64))
+            total += (w * m).sum(dtype=np.uint64)
+    assert int(total) == int(kat["msca_all_sum"])
+
+
+def test_trim_golden(kat, kat_db):
+    quals = unpack_strings(kat["qual_qual_data"], kat["qual_qual_off"])
+    seqs = unpack_strings(kat["qual_seq_data"], kat["qual_seq_off"])
+    # the reference trims over seq.length(); quals may be longer: cut them to the read length
+    q = [qq[:len(s)] for qq, s in zip(quals, seqs)]
+    data, off = concat_reads(q)
+    start, stop, keep = kat_db.trim(data, off)
+    exp = kat["qual_out"]
+    assert np.array_equal(keep.astype(np.int64), exp[:, 0])
+    called = exp[:, 0] == 1
+    assert np.array_equal(start[called], exp[called, 1])
+    assert np.array_equal(stop[called], exp[called, 2])
+
+
+def test_trim_then_classify_golden(kat, kat_db):
+    quals = unpack_strings(kat["qual_qual_data"], kat["qual_qual_off"])
+    seqs = unpack_strings(kat["qual_seq_data"], kat["qual_seq_off"])
+    qd, off = concat_reads([qq[:len(s)] for qq, s in zip(quals, seqs)])
+    sd, off2 = concat_reads(seqs)
+    assert np.array_equal(off, off2)
+    start, stop, keep = kat_db.trim(qd, off)
+    s = kat_db.sample()
+    final = s.classify(sd, off, start, stop)
+    exp = kat["qual_out"]
+    called = exp[:, 0] == 1
+    assert np.array_equal(final[called].astype(np.int64), exp[called, 3])
+    s.close()
+
+
+def test_process_read_golden(kat, kat_db):
+    reads = unpack_strings(kat["reads_data"], kat["reads_off"])
+    data, off = concat_reads(reads)
+    s = kat_db.sample()
+    final = s.classify(data, off)
+    assert np.array_equal(final.astype(np.int64), kat["reads_final"])
+    g, u = s.end()
+    rc = kat["reads_counts"]
+    eg = np.zeros_like(g); eu = np.zeros_like(u)
+    eg[rc[:, 0]] = rc[:, 1]; eu[rc[:, 0]] = rc[:, 2]
+    assert np.array_equal(g, eg)
+    assert np.array_equal(u, eu)
+    s.close()
+
+
+# ------------------------------------------------------------------ seeded runs against the oracle
+@pytest.fixture(scope="module")
+def seeded():
+    parent, cum, keys, targets = small_db(1e-3)
+    odb = oracle_db(parent, keys, targets, 20)
+    db = KmerDB(keys, targets, parent, k=K, log2_slots=20)
+    yield parent, cum, keys, targets, odb, db
+    db.close()
+
+
+@pytest.mark.parametrize("read_len", [150, 250, 31, 30, 29])
+def test_seeded_reads_vs_oracle(seeded, read_len):
+    parent, cum, keys, targets, odb, db = seeded
+    n = 20000
+    bases = synth.reads(cum, parent, n, read_len, K)
+    off = synth.fixed_offsets(n, read_len)
+    os_ = ob.OracleSample(odb)
+    exp = os_.classify(bases, off)
+    eg, eu = os_.counts()
+    s = db.sample()
+    got = s.classify(bases, off)
+    assert np.array_equal(got, exp)
+    g, u = s.end()
+    assert np.array_equal(g, eg) and np.array_equal(u, eu)
+    st, est = s.stats(), os_.stats()
+    assert st["reads"] == n and st["lookups"] == est["lookups"] and st["hits"] == est["hits"]
+    if read_len >= 150:
+        assert st["hits"] > 0 and (exp > 1).sum() > n // 4
+    s.close()
+
+
+def test_probe_counts_match_on_reference_geometry(seeded):
+    parent, cum, keys, targets, odb, _ = seeded
+    db = KmerDB(keys, targets, parent, k=K, log2_slots=20, flags=KID_FLAG_HOST_BUILD)
+    n = 5000
+    bases = synth.reads(cum, parent, n, 150, K, r0=777)
+    off = synth.fixed_offsets(n, 150)
+    os_ = ob.OracleSample(odb)
+    os_.classify(bases, off)
+    s = db.sample()
+    s.classify(bases, off, want_final=False)
+    assert s.stats()["probes"] == os_.stats()["probes"]
+    s.close(); db.close()
+
+
+def test_batching_does_not_change_results(seeded):
+    parent, cum, keys, targets, odb, db = seeded
+    n, L = 9000, 150
+    bases = synth.reads(cum, parent, n, L, K, r0=123)
+    off = synth.fixed_offsets(n, L)
+    s1 = db.sample()
+    f1 = s1.classify(bases, off)
+    g1, u1 = s1.end()
+    s2 = db.sample()
+    parts = []
+    for a, b in ((0, 1), (1, 4000), (4000, 4001), (4001, n)):
+        parts.append(s2.classify(bases, off[a:b + 1]))  # absolute offsets into the same buffer
+    s2.classify(bases, off[0:1])  # empty batch
+    g2, u2 = s2.end()
+    assert np.array_equal(np.concatenate(parts), f1)
+    assert np.array_equal(g1, g2) and np.array_equal(u1, u2)
+    # reset really resets
+    s2.reset()
+    g3, u3 = s2.end()
+    assert g3.sum() == 0 and u3.sum() == 0
+    s1.close(); s2.close()
+
+
+def test_device_resident_fixed_layout(seeded):
+    parent, cum, keys, targets, odb, db = seeded
+    lib = kmer_id_amd.load()
+    n, L = 7000, 150
+    bases = synth.reads(cum, parent, n, L, K, r0=55)
+    d_b, d_o = C.c_void_p(), C.c_void_p()
+    _lib = kmer_id_amd._lib
+    _lib.check(lib.kid_dev_alloc(0, bases.size + 32, C.byref(d_b)))
+    _lib.check(lib.kid_dev_alloc(0, n * 4, C.byref(d_o)))
+    _lib.check(lib.kid_dev_upload(0, d_b, bases.ctypes.data_as(C.c_void_p), bases.size))
+    s = db.sample()
+    s.classify_fixed_device(d_b.value, L, n, d_out=d_o.value)
+    _lib.check(lib.kid_dev_sync(0))
+    got = np.empty(n, np.uint32)
+    _lib.check(lib.kid_dev_download(0, got.ctypes.data_as(C.c_void_p), d_o, n * 4))
+    os_ = ob.OracleSample(odb)
+    exp = os_.classify(bases, synth.fixed_offsets(n, L))
+    assert np.array_equal(got, exp)
+    g, u = s.end()
+    eg, eu = os_.counts()
+    assert np.array_equal(g, eg) and np.array_equal(u, eu)
+    lib.kid_dev_free(0, d_b); lib.kid_dev_free(0, d_o)
+    s.close()
+
+
+def test_ragged_long_and_adversarial_reads(seeded):
+    parent, cum, keys, targets, odb, db = seeded
+    rng = np.random.default_rng(5)
+    kseq = [synth.key_to_seq(int(x)).encode() for x in keys[rng.integers(0, keys.size, 64)]]
+    reads = [b"", b"A", b"ACGT" * 7, b"N" * 200, b"acgtn" * 50]
+    for L in (959, 960, 961, 989, 990, 991, 1919, 1920, 1949, 1950, 1951, 5000, 16383):
+        s = bytearray(rng.choice(list(b"ACGT"), L).tolist())
+        # hits straddling the 960-k-mer segment boundaries and the read ends
+        for p in (0, 930, 931, 945, 959, 960, 961, 975, 1890, 1919, 1920, L - 30):
+            if 0 <= p <= L - 30:
+                s[p:p + 30] = kseq[(p + L) % 64]
+        if L > 1000:
+            s[500] = ord("N")
+        reads.append(bytes(s))
+    for i in range(300):
+        L = int(rng.integers(1, 400))
+        s = bytearray(rng.choice(list(b"ACGTacgtNRY-"), L, p=[.2, .2, .2, .2, .04, .04, .04, .04, .01, .01, .01, .01]).tolist())
+        if L >= 30 and i % 2:
+            p = int(rng.integers(0, L - 29))
+            s[p:p + 30] = kseq[i % 64]
+        reads.append(bytes(s))
+    data, off = concat_reads(reads)
+    os_ = ob.OracleSample(odb)
+    exp = os_.classify(data, off)
+    s = db.sample()
+    got = s.classify(data, off)
+    assert np.array_equal(got, exp)
+    g, u = s.end()
+    eg, eu = os_.counts()
+    assert np.array_equal(g, eg) and np.array_equal(u, eu)
+    assert s.stats()["lookups"] == os_.stats()["lookups"]
+    s.close()
+
+
+def test_start_stop_outside_read_is_an_error(seeded):
+    parent, cum, keys, targets, odb, db = seeded
+    bases = synth.reads(cum, parent, 4, 150, K)
+    off = synth.fixed_offsets(4, 150)
+    s = db.sample()
+    with pytest.raises(kmer_id_amd.KidError):
+        s.classify(bases, off, np.array([0, 0, 0, 0], np.int32), np.array([149, 150, 149, 149], np.int32))
+    s.close()
+
+
+# ------------------------------------------------------------------ variants of the sibling programs
+def test_probe_cap_m3(seeded):
+    """kmer_read_m3.cpp:232: lookups give up after 16 probes; geometry must be the sequential one"""
+    parent, cum, keys, targets, _, _ = seeded
+    n = 3600  # 2^12 cells at load 0.88: many keys sit deeper than 16 probes
+    odb = oracle_db(parent, keys[:n], targets[:n], 12, max_probes=16)
+    odb0 = oracle_db(parent, keys[:n], targets[:n], 12, max_probes=0)
+    db = KmerDB(keys[:n], targets[:n], parent, k=K, log2_slots=12, max_probes=16)
+    assert db.info.host_built == 1
+    q = np.concatenate([keys[:n], keys[n:n + 2000]])
+    t, p = db.lookup(q, with_probes=True)
+    et, ep = odb.get(q, with_probes=True)
+    assert np.array_equal(t, et) and np.array_equal(p, ep)
+    assert (et[:n] == 0).sum() > 0 and p.max() == 16
+    assert not np.array_equal(et, odb0.get(q))
+    bases = synth.reads(synth.cumulative(np.bincount(targets[:n], minlength=parent.size)), parent, 3000, 150, K)
+    off = synth.fixed_offsets(3000, 150)
+    os_ = ob.OracleSample(odb)
+    exp = os_.classify(bases, off)
+    s = db.sample()
+    assert np.array_equal(s.classify(bases, off), exp)
+    g, u = s.end(); eg, eu = os_.counts()
+    assert np.array_equal(g, eg) and np.array_equal(u, eu)
+    s.close(); db.close()
+
+
+def test_u_is_t_flag_vf6(seeded):
+    parent, cum, keys, targets, _, _ = seeded
+    n = 2000
+    bases = synth.reads(cum, parent, n, 150, K, r0=999).copy()
+    tpos = np.flatnonzero(bases == ord("T"))
+    bases[tpos[::3]] = ord("U")
+    tpos = np.flatnonzero(bases == ord("t"))
+    bases[tpos[::2]] = ord("u")
+    off = synth.fixed_offsets(n, 150)
+    for flags in (0, KID_FLAG_U_IS_T):
+        odb = oracle_db(parent, keys, targets, 20, flags=flags)
+        db = KmerDB(keys, targets, parent, k=K, log2_slots=20, flags=flags)
+        os_ = ob.OracleSample(odb)
+        exp = os_.classify(bases, off)
+        s = db.sample()
+        assert np.array_equal(s.classify(bases, off), exp)
+        g, u = s.end(); eg, eu = os_.counts()
+        assert np.array_equal(g, eg) and np.array_equal(u, eu)
+        if flags:
+            assert (exp > 0).sum() > n // 4
+        s.close(); db.close()
+
+
+def test_mito_taxonomy_large_ntar_path(seeded):
+    """17227 targets: gcount leaves the LDS histogram for the run-length + global-atomic path"""
+    parent, cnt = synth.load_taxonomy("mito")
+    cum = synth.cumulative(synth.scaled_counts(cnt, 2e-3))
+    keys, targets = synth.db_keys(cum, K, seed=0x317)
+    odb = oracle_db(parent, keys, targets, 18)
+    db = KmerDB(keys, targets, parent, k=K, log2_slots=18)
+    assert db.info.tree_depth == 6
+    n = 10000
+    bases = synth.reads(cum, parent, n, 150, K, db_seed=0x317)
+    off = synth.fixed_offsets(n, 150)
+    os_ = ob.OracleSample(odb)
+    exp = os_.classify(bases, off)
+    s = db.sample()
+    assert np.array_equal(s.classify(bases, off), exp)
+    g, u = s.end(); eg, eu = os_.counts()
+    assert np.array_equal(g, eg) and np.array_equal(u, eu)
+    s.close(); db.close()
+
+
+def test_deep_tree_uses_climb_fallback():
+    """a 40-level chain with side branches does not fit the 8-entry ancestor rows"""
+    ntar = 400
+    parent = np.ones(ntar, np.int32)
+    for i in range(2, 42):
+        parent[i] = i - 1 if i > 2 else 1      # chain 2 <- 3 <- ... <- 41
+    for i in range(42, ntar):
+        parent[i] = 2 + (i * 7) % 40           # side branches hanging off the chain
+    cnt = np.zeros(ntar, np.int64); cnt[2:] = 5
+    cum = synth.cumulative(cnt)
+    keys, targets = synth.db_keys(cum, K, seed=9)
+    odb = oracle_db(parent, keys, targets, 14)
+    db = KmerDB(keys, targets, parent, k=K, log2_slots=14)
+    assert db.info.tree_depth > 8
+    rng = np.random.default_rng(1)
+    x = rng.integers(1, ntar, 20000).astype(np.int32); y = rng.integers(1, ntar, 20000).astype(np.int32)
+    exp = np.array([odb.msca(a, b) for a, b in zip(x.tolist(), y.tolist())], np.int32)
+    assert np.array_equal(db.msca(x, y), exp)
+    n = 4000
+    bases = synth.reads(cum, parent, n, 150, K, db_seed=9)
+    off = synth.fixed_offsets(n, 150)
+    os_ = ob.OracleSample(odb)
+    e = os_.classify(bases, off)
+    s = db.sample()
+    assert np.array_equal(s.classify(bases, off), e)
+    g, u = s.end(); eg, eu = os_.counts()
+    assert np.array_equal(g, eg) and np.array_equal(u, eu)
+    s.close(); db.close()
+
+
+def test_depth8_tree_row_encoding():
+    """fungal-style taxonomy: 8 ranks below root (kmer_read_vf6 DBs)"""
+    ntar = 3000
+    rng = np.random.default_rng(3)
+    parent = np.ones(ntar, np.int32)
+    depth = np.zeros(ntar, np.int64)
+    for i in range(2, ntar):
+        p = int(rng.integers(1, i)) if i > 2 else 1
+        while depth[p] >= 8:
+            p = int(parent[p])
+        parent[i] = p
+        depth[i] = depth[p] + 1 if p != 1 else 1
+    assert depth.max() == 8
+    cnt = np.zeros(ntar, np.int64); cnt[2:] = 2
+    cum = synth.cumulative(cnt)
+    keys, targets = synth.db_keys(cum, K, seed=11)
+    odb = oracle_db(parent, keys, targets, 15)
+    db = KmerDB(keys, targets, parent, k=K, log2_slots=15)
+    assert db.info.tree_depth == 8
+    deep = np.flatnonzero(depth >= 7).astype(np.int32)
+    x = np.concatenate([rng.integers(1, ntar, 30000).astype(np.int32), np.repeat(deep, 8)[:20000]])
+    y = np.concatenate([rng.integers(1, ntar, 30000).astype(np.int32), np.tile(deep, 8)[:20000]])
+    n = min(x.size, y.size); x, y = x[:n], y[:n]
+    exp = np.array([odb.msca(a, b) for a, b in zip(x.tolist(), y.tolist())], np.int32)
+    assert np.array_equal(db.msca(x, y), exp)
+    nr = 6000
+    bases = synth.reads(cum, parent, nr, 250, K, db_seed=11)
+    off = synth.fixed_offsets(nr, 250)
+    os_ = ob.OracleSample(odb)
+    e = os_.classify(bases, off)
+    s = db.sample()
+    assert np.array_equal(s.classify(bases, off), e)
+    g, u = s.end(); eg, eu = os_.counts()
+    assert np.array_equal(g, eg) and np.array_equal(u, eu)
+    s.close(); db.close()
+
+
+def test_duplicate_keys_first_wins_on_gpu_build():
+    parent, cum, keys, targets = small_db(2e-4)
+    rng = np.random.default_rng(8)
+    # every key three times with different targets, shuffled; ordinal order decides
+    k3 = np.concatenate([keys, keys, keys])
+    t3 = np.concatenate([targets, (targets + 3) % 5000 + 2, (targets + 11) % 5000 + 2]).astype(np.uint32)
+    perm = rng.permutation(k3.size)
+    k3, t3 = k3[perm], t3[perm]
+    t3[::17] = 0  # target-0 entries are invisible
+    odb = oracle_db(parent, k3, t3, 18)
+    db = KmerDB(k3, t3, parent, k=K, log2_slots=18)
+    assert db.info.host_built == 0
+    exp = odb.get(keys)
+    assert np.array_equal(db.lookup(keys), exp)
+    db.close()
+
+
+def test_table_full_and_bad_inputs():
+    parent, cum, keys, targets = small_db(2e-4)
+    with pytest.raises(kmer_id_amd.KidError) as e:
+        KmerDB(keys[:1000], targets[:1000], parent, log2_slots=10)  # 1000 > 1024 - 32
+    assert e.value.status == -4
+    bad = parent.copy(); bad[10] = 11; bad[11] = 10
+    with pytest.raises(kmer_id_amd.KidError) as e:
+        KmerDB(keys[:10], targets[:10], bad, log2_slots=10)
+    assert e.value.status == -5
+    with pytest.raises(kmer_id_amd.KidError) as e:
+        KmerDB(keys[:10], np.full(10, 6000, np.uint32), parent, log2_slots=10)
+    assert e.value.status == -7
