@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- paired reads classified / second on the bact10-synth DB (BASELINE.json).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  Every rank holds a full replica of the database in its HBM
+(2^30 cells x 16 B = 16 GiB table, 108 585 519 synthetic canonical 30-mers laid
+over the reference's real bact10 taxonomy) and classifies its own shard of the
+reads (weak scaling: PAIRS_PER_STEP pairs per rank per step).  A "step" is one
+pass of the hot path (kid_classify_fixed_device -> kid_classify_kernel) over one
+batch of 150-bp reads that is already resident in HBM.  After the K steps the
+sample is closed inside the timed region: ucount from the seen-bitmap and, for
+N > 1, the RCCL merge (bitmap slices all_to_all + one all_reduce).
+
+Rank 0 prints ONE JSON line (metric, roofline, cpu_baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import kmer_id_amd  # noqa: E402
+from kmer_id_amd import KmerDB, synth  # noqa: E402
+from kmer_id_amd.dist import merge_sample  # noqa: E402
+
+K = 30
+READ_LEN = 150
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def build_db(device, scale, log2_slots, keep_host_copy):
+    """bact10-synth: keys generated on the device, table built on the device."""
+    parent, cnt = synth.load_taxonomy("bact10")
+    cum = synth.cumulative(synth.scaled_counts(cnt, scale))
+    n = int(cum[-1])
+    lib = kmer_id_amd.load()
+    d_keys = torch.empty(n, dtype=torch.int64, device=device)
+    d_targets = torch.empty(n, dtype=torch.int32, device=device)
+    import ctypes as C
+    kmer_id_amd._lib.check(lib.kid_synth_db_keys_device(synth.DB_SEED, K, cum.ctypes.data_as(C.c_void_p), parent.size, 0, n,
+                                                        C.c_void_p(d_keys.data_ptr()), C.c_void_p(d_targets.data_ptr()),
+                                                        device.index))
+    t0 = time.time()
+    db = KmerDB.from_device(d_keys.data_ptr(), d_targets.data_ptr(), n, parent, k=K, log2_slots=log2_slots, device=device.index)
+    build_s = time.time() - t0
+    host = None
+    if keep_host_copy:
+        host = (d_keys.cpu().numpy().view(np.uint64), d_targets.cpu().numpy().view(np.uint32))
+    del d_keys, d_targets
+    torch.cuda.empty_cache()
+    return db, parent, cum, build_s, host
+
+
+def gen_reads(device, cum, parent, r0, n_reads):
+    import ctypes as C
+    lib = kmer_id_amd.load()
+    buf = torch.empty(n_reads * READ_LEN + 64, dtype=torch.uint8, device=device)
+    kmer_id_amd._lib.check(lib.kid_synth_reads_device(synth.DB_SEED, synth.READ_SEED, K, cum.ctypes.data_as(C.c_void_p),
+                                                      parent.ctypes.data_as(C.c_void_p), parent.size, r0, n_reads, READ_LEN,
+                                                      C.c_void_p(buf.data_ptr()), device.index))
+    return buf
+
+
+def cpu_baseline(host_keys, parent, cum, log2_slots, n_reads):
+    """The oracle (plain-C restatement of the reference's loop, 24-byte cells, one thread) on the
+    first n_reads reads of the same workload, same DB, on this host's cores."""
+    from oracle import binding as ob
+    keys, targets = host_keys
+    t0 = time.time()
+    odb = ob.OracleDB(parent.size, K, log2_slots, parent=parent)
+    odb.add(keys, targets)
+    build_s = time.time() - t0
+    os_ = ob.OracleSample(odb)
+    bases = synth.reads(cum, parent, n_reads, READ_LEN, K)
+    off = synth.fixed_offsets(n_reads, READ_LEN)
+    warm = min(n_reads, 2000)
+    os_.classify_timed(bases[:warm * READ_LEN], off[:warm + 1])
+    os_.reset()
+    sec = os_.classify_timed(bases, off)
+    st = os_.stats()
+    g, u = os_.counts()
+    odb.close()
+    return {"value": (n_reads / 2) / sec, "unit": "paired reads/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads (%d pairs) of the same synthetic stream, oracle/kmer_oracle.c, 1 thread, "
+                      "same %d-key DB in a 2^%d-cell table of 24-byte cells; %.1f s classify, %.1f s table build; "
+                      "%.2f M lookups/s" % (n_reads, n_reads // 2, keys.size, log2_slots, sec, build_s, st["lookups"] / sec / 1e6)}, (g, u)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per rank per step (configs[1]: 1M pairs)")
+    ap.add_argument("--scale", type=float, default=1.0, help="DB scale (1.0 = 108.6 M k-mers)")
+    ap.add_argument("--log2-slots", type=int, default=30)
+    ap.add_argument("--cpu-reads", type=int, default=300_000, help="reads of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--batches", type=int, default=4, help="distinct resident read batches cycled over the steps")
+    ap.add_argument("--gather", type=int, default=1, help="also measure the random 16-byte gather ceiling")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; no HIP device is visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    n_reads = 2 * args.pairs  # R1 + R2, classified independently (newkmer_10nx.cpp:1029-1031)
+    want_cpu = (rank == 0 and world == 1 and args.cpu_reads > 0)
+    log("building bact10-synth DB (scale %g, 2^%d cells) ..." % (args.scale, args.log2_slots))
+    db, parent, cum, build_s, host_keys = build_db(device, args.scale, args.log2_slots, want_cpu)
+    info = db.info
+    log("DB: %d entries, %d cells occupied, table %.1f GiB, GPU build %.2f s" % (info.n_entries, info.n_occupied,
+                                                                                 info.table_bytes / 2**30, build_s))
+    nb = max(1, min(args.batches, args.steps + args.warmup))
+    batches = [gen_reads(device, cum, parent, (rank * nb + b) * n_reads, n_reads) for b in range(nb)]
+    out_final = torch.empty(n_reads, dtype=torch.int32, device=device)
+    sample = db.sample()
+    stream = torch.cuda.current_stream(device)
+
+    def step(i):
+        sample.classify_fixed_device(batches[i % nb].data_ptr(), READ_LEN, n_reads, d_out=out_final.data_ptr(),
+                                     stream=stream.cuda_stream)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(device)
+    sample.reset()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        step(i)
+        ev[i][1].record(stream)
+    # close the sample: ucount from the seen-bitmap (+ RCCL merge over the ranks)
+    if world > 1:
+        g, u = merge_sample(sample, device)
+    else:
+        g, u = sample.end()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    st = sample.stats()
+    total_reads = st["reads"]
+    assert total_reads == args.steps * n_reads, (total_reads, args.steps * n_reads)
+    assert int(g.sum()) == args.steps * n_reads * world, "gcount does not add up to the reads processed"
+    kern_s = sum(kernel_ms) / 1e3
+    probes_per_launch = st["probes"] / args.steps
+    avg_kernel_s = kern_s / args.steps
+    achieved = probes_per_launch * 16 / avg_kernel_s / 1e9
+
+    extra = {}
+    if args.gather and rank == 0:
+        for inflight in (1, 4):
+            ms, loads = db.gather_ceiling(n_loads=1 << 29, inflight=inflight, iters=3)
+            extra["gather16B_%d_inflight_GBps" % inflight] = round(loads * 16 / (ms / 1e3) / 1e9, 1)
+            extra["gather16B_%d_inflight_Gloads_per_s" % inflight] = round(loads / (ms / 1e3) / 1e9, 2)
+
+    cpu = None
+    if want_cpu:
+        log("CPU baseline: oracle, 1 thread, %d reads ..." % args.cpu_reads)
+        cpu, (cg, cu) = cpu_baseline(host_keys, parent, cum, args.log2_slots, args.cpu_reads)
+        # the same reads through the GPU path must give the same counts
+        chk = db.sample()
+        hb = synth.reads(cum, parent, args.cpu_reads, READ_LEN, K)
+        chk.classify(hb, synth.fixed_offsets(args.cpu_reads, READ_LEN), want_final=False)
+        gg, gu = chk.end()
+        cpu["gpu_equals_cpu_on_sample"] = bool(np.array_equal(gg, cg) and np.array_equal(gu, cu))
+        chk.close()
+
+    if rank == 0:
+        pairs_total = args.steps * args.pairs * world
+        line = {
+            "metric": "paired reads classified/sec on bact10 DB",
+            "value": pairs_total / elapsed,
+            "unit": "paired reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "bact10-synth DB (%d 30-mers on the real bact10 taxonomy, 2^%d-cell table resident in HBM), "
+                                   "%d synthetic 150 bp read pairs per GPU per step, reads resident in HBM" % (
+                                       info.n_entries, args.log2_slots, args.pairs),
+                       "db_scale": args.scale, "pairs_per_gpu_per_step": args.pairs, "read_len": READ_LEN, "k": K,
+                       "sharding": "reads sharded over %d rank(s), DB replicated" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "kid_classify_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "algorithmic_bytes_per_launch": probes_per_launch * 16,
+                         "lookups_per_launch": st["lookups"] / args.steps, "probes_per_launch": probes_per_launch,
+                         "lookups_per_s": st["lookups"] / kern_s, "kernel_only_pairs_per_s": args.pairs / avg_kernel_s,
+                         **extra},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    sample.close()
+    db.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -83,7 +83,8 @@ class KidError(RuntimeError):
 
 
 def lib_path():
-    return _build.LIB
+    # KMER_ID_AMD_LIB: an alternative build of the same library (A/B experiments)
+    return os.environ.get("KMER_ID_AMD_LIB") or _build.LIB
 
 
 def load(build_if_missing=True):

@@ -20,6 +20,27 @@
 #define KID_SEG_KMERS 960  // k-mers per read segment: 960 + 30 bases + 15 alignment slack <= 64 chunks of 16 B
 #define KID_WAVE_LDS_WORDS 100 // 66 packed-base words + 34 invalid-mask words per wave
 
+typedef uint32_t kid_u4 __attribute__((ext_vector_type(4)));
+
+// One table cell.  Non-temporal: a probe touches a random 16 bytes of a 16 GiB table once, so
+// the line is not worth keeping in L2 / Infinity Cache (measured: tools/gather_policy.hip,
+// 49 -> 54 G random cells/s on a 16 GiB region).
+#ifndef KID_NT
+#define KID_NT 1
+#endif
+#ifndef KID_PAIR
+#define KID_PAIR 0
+#endif
+__device__ __forceinline__ uint4 kid_load_cell(const uint4 *table, uint32_t idx)
+{
+#if KID_NT
+    const kid_u4 v = __builtin_nontemporal_load(reinterpret_cast<const kid_u4 *>(table) + idx);
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return table[idx];
+#endif
+}
+
 struct KidDevDb {
     const uint4 *table;
     uint64_t nslots;
@@ -242,6 +263,40 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
 #pragma unroll
                 for (int u = 0; u < U; u++) { tgt[u] = 0; slot[u] = 0; step[u] = 0; rp[u] = 0; }
                 bool any = false;
+#if KID_PAIR
+                // probes 1 and 2 (cells h and h+1, the same 64-byte sector 3 times out of 4) are
+                // fetched together: one memory round trip settles ~99 % of the lookups
+                {
+                    uint4 c0[U], c1[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        c0[u] = make_uint4(0, 0, 0, 0);
+                        c1[u] = make_uint4(0, 0, 0, 0);
+                        if (act[u]) {
+                            c0[u] = kid_load_cell(db.table, hlo[u] & db.slot_mask);
+                            c1[u] = kid_load_cell(db.table, (hlo[u] + 1u) & db.slot_mask);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        if (act[u]) {
+                            const uint32_t klo = (uint32_t)key[u], khi = (uint32_t)(key[u] >> 32);
+                            step[u] = 1;
+                            rp[u] = 1;
+                            if (c0[u].z == 0) act[u] = false;
+                            else if (c0[u].x == klo && c0[u].y == khi) { tgt[u] = c0[u].z; slot[u] = hlo[u] & db.slot_mask; act[u] = false; }
+                            else if (db.max_probes == 1) act[u] = false;
+                            else {
+                                step[u] = 2;
+                                rp[u] = 3;
+                                if (c1[u].z == 0) act[u] = false;
+                                else if (c1[u].x == klo && c1[u].y == khi) { tgt[u] = c1[u].z; slot[u] = (hlo[u] + 1u) & db.slot_mask; act[u] = false; }
+                                else if (db.max_probes == 2) act[u] = false;
+                            }
+                        }
+                    }
+                }
+#endif
 #pragma unroll
                 for (int u = 0; u < U; u++) any |= act[u];
                 while (any) {
@@ -251,7 +306,7 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
                     for (int u = 0; u < U; u++) {
                         idx[u] = (hlo[u] + (uint32_t)rp[u]) & db.slot_mask;
                         c[u] = make_uint4(0, 0, 0, 0);
-                        if (act[u]) c[u] = db.table[idx[u]];
+                        if (act[u]) c[u] = kid_load_cell(db.table, idx[u]);
                     }
                     any = false;
 #pragma unroll

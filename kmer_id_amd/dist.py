@@ -1,0 +1,56 @@
+"""Multi-GPU merge of one sample's counters: one process per GPU, reads sharded
+over the ranks, the database replicated in every GPU's HBM.
+
+  gcount (reads per target)          additive            -> all_reduce(SUM)
+  ucount (distinct DB k-mers seen)   NOT additive        -> ranks exchange slices of the
+        per-cell "seen" bitmap (all_to_all: every xGMI link carries one slice), OR them,
+        count their own slice by target, and the partial counts ride in the same
+        all_reduce as gcount.
+
+The exchange itself is plain torch.distributed ("nccl" = RCCL on ROCm; "gloo" on
+CPU for the tests); the classification path has no collective in it.
+"""
+import functools
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def merge_counts(gcount, seen, count_slice, group=None):
+    """gcount: int64[ntar] tensor; seen: uint8[nbytes] tensor (this rank's bitmap), both on the
+    backend's device.  count_slice(byte_begin, byte_end, merged_slice_uint8) -> int64[ntar]
+    tensor with the ucount contribution of that slice of table cells.
+    Returns (gcount_total, ucount_total), identical on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    nbytes = seen.numel()
+    if world == 1:
+        return gcount.clone(), count_slice(0, nbytes, seen)
+    if nbytes % (world * 4) != 0:
+        raise ValueError("bitmap of %d bytes does not split into %d 4-byte aligned slices" % (nbytes, world))
+    sl = nbytes // world
+    recv = torch.empty_like(seen)
+    dist.all_to_all_single(recv, seen, group=group)  # chunk j of recv = slice `rank` of rank j's bitmap
+    merged = functools.reduce(torch.bitwise_or, recv.view(world, sl).unbind(0))
+    part = count_slice(rank * sl, (rank + 1) * sl, merged.contiguous())
+    both = torch.stack([gcount, part.to(gcount.device)])
+    dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
+    return both[0], both[1]
+
+
+def merge_sample(sample, device, group=None):
+    """Sample-level wrapper for the HIP path: -> (gcount, ucount) numpy int64 arrays."""
+    ntar = sample.ntar
+    g = torch.from_numpy(sample.gcount()).to(device)
+    nbytes = sample.seen_bytes()
+    seen = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    sample.seen_export(0, nbytes, dst_ptr=seen.data_ptr(), on_device=True)
+
+    def count_slice(b0, b1, merged):
+        if b1 - b0 != nbytes:  # fold the other ranks' bits of my slice into my bitmap, then count it
+            sample.seen_or(b0, merged.data_ptr(), nbytes=b1 - b0, on_device=True)
+        return torch.from_numpy(sample.ucount_range(b0 * 8, b1 * 8)).to(device)
+
+    gt, ut = merge_counts(g, seen, count_slice, group)
+    return gt.cpu().numpy().astype(np.int64), ut.cpu().numpy().astype(np.int64)

@@ -35,7 +35,9 @@ def load():
         "ko_msca": (i32, [vp, i32, i32]),
         "ko_msca_checksum": (u64, [vp]),
         "ko_db_add_kmer": (i32, [vp, u64, C.c_uint32]),
+        "ko_db_add_batch": (i32, [vp, vp, vp, u64]),
         "ko_db_get": (C.c_uint32, [vp, u64, vp]),
+        "ko_classify_batch_timed": (C.c_double, [vp, vp, vp, vp, vp, u64]),
         "ko_db_get_batch": (None, [vp, vp, u64, vp, vp]),
         "ko_db_process_kmer": (i32, [vp, C.c_char_p, C.c_size_t, C.c_uint32]),
         "ko_db_probe_line": (i32, [vp, C.c_char_p, C.c_size_t]),
@@ -84,10 +86,8 @@ class OracleDB:
     def add(self, keys, targets):
         keys = np.ascontiguousarray(keys, np.uint64)
         targets = np.ascontiguousarray(targets, np.uint32)
-        add = self.lib.ko_db_add_kmer
-        for key, t in zip(keys.tolist(), targets.tolist()):
-            if add(self.h, key, t) != 0:
-                raise RuntimeError("out of memory in table")
+        if self.lib.ko_db_add_batch(self.h, _p(keys), _p(targets), keys.size) != 0:
+            raise RuntimeError("out of memory in table")
 
     def get(self, keys, with_probes=False):
         keys = np.ascontiguousarray(keys, np.uint64)
@@ -136,6 +136,16 @@ class OracleSample:
         out = np.empty(n, np.uint32)
         self.lib.ko_classify_batch(self.h, _p(bases), _p(offsets), _p(start), _p(stop), n, _p(out))
         return out
+
+    def classify_timed(self, bases, offsets):
+        """whole reads, single thread; -> seconds"""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        n = offsets.size - 1
+        lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+        start = np.zeros(n, np.int32)
+        stop = (lens - 1).astype(np.int32)
+        return self.lib.ko_classify_batch_timed(self.h, _p(bases), _p(offsets), _p(start), _p(stop), n)
 
     def counts(self):
         n = self.db.ntar

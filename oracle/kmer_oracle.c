@@ -23,6 +23,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <time.h>
 #include <zlib.h>
 
 #define KO_FLAG_U_IS_T 1u /* kmer_read_vf6.cpp:496-500,521-525: U/u counts as T */
@@ -46,6 +48,8 @@ typedef struct ko_db {
     uint64_t nslots, size;
     uint64_t mask, hi_c, hi_g, hi_t; /* newkmer_10nx.cpp:76-79 */
     ko_cell *cells;
+    uint64_t cells_bytes;
+    int cells_mapped;
     int32_t *parent; /* Tree1::parent              newkmer_10nx.cpp:98  */
     uint32_t *mark;  /* scratch for msca (replaces the per-call std::set) */
     uint32_t mark_gen;
@@ -89,11 +93,23 @@ ko_db *ko_db_new(int ntar, int k, int log2_slots, int max_probes, uint32_t flags
     db->hi_c = 1ULL << ((k - 1) * 2);
     db->hi_g = 2ULL << ((k - 1) * 2);
     db->hi_t = 3ULL << ((k - 1) * 2);
-    db->cells = (ko_cell *)calloc(db->nslots, sizeof(ko_cell));
+    /* zero-filled like HashClear() (:199-202); big tables come from mmap with
+     * transparent huge pages so that the 24 GiB zero-fill takes seconds, not minutes */
+    db->cells_bytes = db->nslots * sizeof(ko_cell);
+    if (db->cells_bytes >= (64u << 20)) {
+        void *m = mmap(NULL, db->cells_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m != MAP_FAILED) {
+            madvise(m, db->cells_bytes, MADV_HUGEPAGE);
+            db->cells = (ko_cell *)m;
+            db->cells_mapped = 1;
+        }
+    }
+    if (!db->cells) db->cells = (ko_cell *)calloc(db->nslots, sizeof(ko_cell));
     db->parent = (int32_t *)malloc(sizeof(int32_t) * (size_t)ntar);
     db->mark = (uint32_t *)calloc((size_t)ntar, sizeof(uint32_t));
     if (!db->cells || !db->parent || !db->mark) {
-        free(db->cells); free(db->parent); free(db->mark); free(db);
+        if (db->cells_mapped) munmap(db->cells, db->cells_bytes); else free(db->cells);
+        free(db->parent); free(db->mark); free(db);
         return NULL;
     }
     for (int i = 0; i < ntar; i++) db->parent[i] = 1; /* every node hangs off root=1 by default */
@@ -103,7 +119,8 @@ ko_db *ko_db_new(int ntar, int k, int log2_slots, int max_probes, uint32_t flags
 void ko_db_free(ko_db *db)
 {
     if (!db) return;
-    free(db->cells); free(db->parent); free(db->mark); free(db);
+    if (db->cells_mapped) munmap(db->cells, db->cells_bytes); else free(db->cells);
+    free(db->parent); free(db->mark); free(db);
 }
 
 uint64_t ko_db_size(const ko_db *db) { return db->size; }
@@ -176,6 +193,13 @@ int ko_db_add_kmer(ko_db *db, uint64_t key, uint32_t target)
             return 0;
         }
     }
+}
+
+int ko_db_add_batch(ko_db *db, const uint64_t *keys, const uint32_t *targets, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; i++)
+        if (ko_db_add_kmer(db, keys[i], targets[i]) != 0) return -1;
+    return 0;
 }
 
 /* ---- Hashtable::getHash, newkmer_10nx.cpp:204-233; probe cap of kmer_read_m3.cpp:232 ---- */
@@ -449,6 +473,17 @@ void ko_classify_batch(ko_sample *s, const uint8_t *bases, const uint64_t *offse
         int f = ko_process_read(s, (const char *)bases + offsets[r], start[r], stop[r], NULL);
         if (final_out) final_out[r] = (uint32_t)f;
     }
+}
+
+/* wall-clock timed form for the cpu_baseline leg of bench.py: seconds for n reads */
+double ko_classify_batch_timed(ko_sample *s, const uint8_t *bases, const uint64_t *offsets,
+                               const int32_t *start, const int32_t *stop, uint64_t n)
+{
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    ko_classify_batch(s, bases, offsets, start, stop, n, NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
 /* ---- process_qual, newkmer_10nx.cpp:714-760 ----

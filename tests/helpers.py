@@ -66,12 +66,7 @@ def small_db(scale, name="bact10", k=K, seed=synth.DB_SEED):
 
 def oracle_db(parent, keys, targets, log2_slots, k=K, max_probes=0, flags=0):
     db = ob.OracleDB(parent.size, k, log2_slots, max_probes, flags, parent=parent)
-    lib = db.lib
-    keys = np.ascontiguousarray(keys, np.uint64)
-    targets = np.ascontiguousarray(targets, np.uint32)
-    for key, t in zip(keys.tolist(), targets.tolist()):
-        if lib.ko_db_add_kmer(db.h, key, t) != 0:
-            raise RuntimeError("out of memory in table")
+    db.add(keys, targets)
     return db
 
 
