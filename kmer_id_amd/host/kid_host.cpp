@@ -1,0 +1,278 @@
+// kid_host.cpp -- see kid_host.h.  Own implementation; the reference lines each piece
+// reproduces are cited next to it.
+#include "kid_host.h"
+
+#include <string.h>
+#include <zlib.h>
+
+#include <fstream>
+#include <sstream>
+
+namespace kidhost {
+
+static const size_t REF_LINE_LIMIT = 0x4000; // BUFLEN, newkmer_10nx.cpp:85
+
+// ---------------------------------------------------------------- tree / strain list
+std::vector<int32_t> load_tree(const std::string &path, int ntar)
+{
+    std::vector<int32_t> parent((size_t)ntar, 1); // Tree1::Tree1, :101-106
+    std::ifstream fin(path);
+    if (!fin) return parent; // the reference does not notice a missing tree file (:973-984)
+    std::string line;
+    int i = 0, j = 0;
+    bool j_valid = false;
+    while (std::getline(fin, line)) {
+        // same extraction the reference performs, so malformed lines behave the same:
+        // a failed first number zeroes i and leaves j alone, a failed second zeroes j
+        std::stringstream ls(line);
+        ls >> i;
+        if (ls) { ls >> j; j_valid = true; }
+        if (!j_valid) continue; // reference reads an uninitialised j here
+        if (j < 0 || j >= ntar) throw Fatal{1, "taxonomy edge names node " + std::to_string(j) + " outside [0," + std::to_string(ntar) + ")"};
+        parent[(size_t)j] = i; // Tree1::add_edge, :112-116
+    }
+    return parent;
+}
+
+bool strain_list_present(const std::string &path)
+{
+    std::ifstream fin(path);
+    return (bool)fin;
+}
+
+// ---------------------------------------------------------------- gz line reader
+GzLines::GzLines(const std::string &path)
+{
+    gz_ = gzopen(path.c_str(), "rb");
+    // gzopen failure: the reference calls gzread(NULL) -> -1 -> error(gzerror(NULL)) -> exit(255)
+    if (!gz_) throw Fatal{255, "cannot open " + path};
+    gzbuffer((gzFile)gz_, 1 << 20);
+    buf_.resize(1 << 20);
+}
+
+GzLines::~GzLines()
+{
+    if (gz_) gzclose((gzFile)gz_);
+}
+
+void GzLines::close()
+{
+    if (gz_) {
+        int rc = gzclose((gzFile)gz_);
+        gz_ = nullptr;
+        if (rc != Z_OK) throw Fatal{255, "failed gzclose"};
+    }
+}
+
+bool GzLines::fill()
+{
+    if (eof_) return false;
+    if (pos_ > 0) { // keep the partial line at the front
+        memmove(buf_.data(), buf_.data() + pos_, end_ - pos_);
+        end_ -= pos_;
+        pos_ = 0;
+    }
+    if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);
+    int got = gzread((gzFile)gz_, buf_.data() + end_, (unsigned)(buf_.size() - end_));
+    if (got < 0) {
+        int err = 0;
+        const char *msg = gzerror((gzFile)gz_, &err);
+        throw Fatal{255, msg ? msg : "gzread failed"};
+    }
+    if (got == 0) { eof_ = true; return false; }
+    end_ += (size_t)got;
+    return true;
+}
+
+bool GzLines::next(const char *&line, size_t &len)
+{
+    size_t scanned = 0;
+    for (;;) {
+        const char *base = buf_.data() + pos_;
+        const char *nl = (const char *)memchr(base + scanned, '\n', end_ - pos_ - scanned);
+        if (nl) {
+            size_t l = (size_t)(nl - base);
+            if (l >= REF_LINE_LIMIT) throw Fatal{255, "Buffer to small for input line lengths"};
+            if (l > 0 && base[l - 1] == '\r') l--;
+            line = base;
+            len = l;
+            pos_ += (size_t)(nl - base) + 1;
+            return true;
+        }
+        scanned = end_ - pos_;
+        if (scanned >= REF_LINE_LIMIT) throw Fatal{255, "Buffer to small for input line lengths"};
+        if (!fill()) return false; // unterminated tail is dropped (:812-813)
+    }
+}
+
+// ---------------------------------------------------------------- probes
+static inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\v' || c == '\f' || c == '\r' || c == '\n'; }
+
+// digits only, at most 9 of them: every integer type in the reference's extraction accepts it
+static inline bool fast_uint(const char *&p, const char *e, uint32_t &out)
+{
+    const char *s = p;
+    uint32_t v = 0;
+    while (p < e && *p >= '0' && *p <= '9') { v = v * 10 + (uint32_t)(*p - '0'); p++; }
+    if (p == s || p - s > 9) return false;
+    out = v;
+    return true;
+}
+
+static void roll_probe(const char *seq, size_t len, uint32_t target, int k, ProbeSet &ps)
+{
+    // process_kmer, :619-661: forward key, upper-case ACGT only, every full window is inserted
+    const uint64_t mask = (1ULL << (2 * k)) - 1;
+    int cpos = 0;
+    uint64_t keyF = 0;
+    for (size_t i = 0; i < len; i++) {
+        int c;
+        switch (seq[i]) {
+        case 'A': c = 0; break;
+        case 'C': c = 1; break;
+        case 'G': c = 2; break;
+        case 'T': c = 3; break;
+        default: c = -1; break;
+        }
+        if (c < 0) { cpos = 0; keyF = 0; continue; }
+        keyF = ((keyF << 2) & mask) | (uint64_t)c;
+        if (++cpos == k) {
+            ps.keys.push_back(keyF);
+            ps.targets.push_back(target);
+            cpos--;
+        }
+    }
+}
+
+ProbeSet load_probes_gz(const std::string &path, int k)
+{
+    ProbeSet ps;
+    GzLines in(path);
+    const char *line;
+    size_t len;
+    std::string tmp, sequence;
+    while (in.next(line, len)) {
+        if (len == 0) continue;
+        // fast path: SEQ,uint,uint,uint,char,uint with nothing else on the line
+        const char *p = line, *e = line + len;
+        const char *s0 = p;
+        while (p < e && *p != ',' && !is_ws(*p)) p++;
+        uint32_t target, org, position, count;
+        bool ok = (p > s0 && p < e && *p == ',');
+        const char *s1 = p;
+        if (ok) { p++; ok = fast_uint(p, e, target) && p < e && *p == ','; }
+        if (ok) { p++; ok = fast_uint(p, e, org) && p < e && *p == ','; }
+        if (ok) { p++; ok = fast_uint(p, e, position) && p < e && *p == ','; }
+        if (ok) { p++; ok = (p < e && *p != ',' && !is_ws(*p)); }
+        if (ok) { p++; ok = (p < e && *p == ','); }
+        if (ok) { p++; ok = fast_uint(p, e, count) && p == e; }
+        if (ok) {
+            roll_probe(s0, (size_t)(s1 - s0), target, k, ps);
+            ps.lines_parsed++;
+            continue;
+        }
+        // anything else: the reference's own extraction decides (:695-697)
+        tmp.assign(line, len);
+        for (char &c : tmp) if (c == ',') c = ' ';
+        std::istringstream ss(tmp);
+        unsigned int t2;
+        int o2, p2, c2;
+        char strand;
+        if (ss >> sequence >> t2 >> o2 >> p2 >> strand >> c2) {
+            roll_probe(sequence.data(), sequence.size(), t2, k, ps);
+            ps.lines_parsed++;
+        }
+    }
+    in.close();
+    return ps;
+}
+
+// ---------------------------------------------------------------- trimming
+bool trim_read(const std::string &seq, const std::string &qual, int k, int &start, int &stop)
+{
+    // process_qual, :714-760.  std::string::at() yields (signed) char on this ABI.
+    const int n = (int)seq.length();
+    if ((int)qual.length() < n) throw Fatal{134, "quality line shorter than its sequence (std::out_of_range in the reference)"};
+    const signed char *q = (const signed char *)qual.data();
+    const signed char cut = 32 + 17;
+    const int wcut = 17 * 4;
+    stop = n - 1;
+    start = 0;
+    while (q[start] < cut && start < stop) start++;
+    while (q[stop] < cut && stop > start) stop--;
+    if (start < stop - 4) {
+        int w = (q[start] - 32) + (q[start + 1] - 32) + (q[start + 2] - 32) + (q[start + 3] - 32);
+        while (w < wcut && start < stop - 4) { w += q[start + 4] - q[start]; start++; }
+    }
+    if (start < stop - 4) {
+        int w = (q[stop] - 32) + (q[stop - 1] - 32) + (q[stop - 2] - 32) + (q[stop - 3] - 32);
+        while (w < wcut && start < stop - 4) { w += q[stop - 4] - q[stop]; stop--; }
+    }
+    return stop - start >= k;
+}
+
+// ---------------------------------------------------------------- FASTQ stream
+FastqStream::FastqStream(const std::string &path, int k) : lines_(path), k_(k) {}
+
+bool FastqStream::fill(ReadBatch &out, size_t max_reads)
+{
+    out.clear();
+    const char *line;
+    size_t len;
+    std::string qual;
+    while (out.size() < max_reads && lines_.next(line, len)) {
+        if (len == 0) continue; // blank lines do not advance the record phase (:788)
+        if (mod4_ == 1) seq_.assign(line, len);
+        else if (mod4_ == 0) acc_.assign(line, len);
+        else if (mod4_ == 3) {
+            qual.assign(line, len);
+            int st, sp;
+            if (trim_read(seq_, qual, k_, st, sp)) {
+                out.bases.insert(out.bases.end(), seq_.begin(), seq_.end());
+                out.offsets.push_back(out.bases.size());
+                out.start.push_back(st);
+                out.stop.push_back(sp);
+                out.acc.push_back(acc_);
+            }
+        }
+        mod4_ = (mod4_ + 1) % 4;
+    }
+    return out.size() > 0;
+}
+
+// ---------------------------------------------------------------- outputs
+void write_result(const std::string &path, const std::vector<int64_t> &gcount, const std::vector<int64_t> &ucount)
+{
+    FILE *f = fopen(path.c_str(), "w");
+    if (!f) return; // an ofstream that failed to open swallows the writes
+    for (size_t i = 0; i < gcount.size(); i++) fprintf(f, "%zu,%lld,%lld\n", i, (long long)gcount[i], (long long)ucount[i]);
+    fclose(f);
+}
+
+ReadSaver::ReadSaver(const std::string &path, int ntar) : seen_((size_t)ntar, 0)
+{
+    f_ = fopen(path.c_str(), "w"); // ofstream::trunc, :1025
+}
+
+ReadSaver::~ReadSaver()
+{
+    if (f_) fclose(f_);
+}
+
+void ReadSaver::add_batch(const ReadBatch &b, const std::vector<uint32_t> &final_targ)
+{
+    for (size_t r = 0; r < b.size(); r++) {
+        const uint32_t t = final_targ[r];
+        if (t > 1 && seen_[t] < 12 && f_) { // SAVENUM, :48,:608
+            const uint8_t *s = b.bases.data() + b.offsets[r] + b.start[r];
+            fprintf(f_, ">%u:", t);
+            fwrite(b.acc[r].data(), 1, b.acc[r].size(), f_);
+            fputc('\n', f_);
+            fwrite(s, 1, (size_t)(b.stop[r] - b.start[r] + 1), f_);
+            fputc('\n', f_);
+        }
+        seen_[t]++;
+    }
+}
+
+} // namespace kidhost

@@ -1,0 +1,96 @@
+// kid_host.h -- host-side C++ of the nk10-compatible program: database text loaders, the
+// FASTQ.gz reader with the reference's line rules, quality trimming and result writers.
+// All classification goes through the C ABI (include/kmer_id_amd.h) to the GPU.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+namespace kidhost {
+
+// What the reference does when it gives up (newkmer_10nx.cpp:87-91 and friends)
+struct Fatal {
+    int exit_code;
+    std::string message;
+};
+
+// ---------------------------------------------------------------- database text files
+// Tree1 after `linestream >> i >> j; add_edge(i,j)` over every line (newkmer_10nx.cpp:973-983).
+// A missing file leaves every node under root, silently, like the reference.
+std::vector<int32_t> load_tree(const std::string &path, int ntar);
+
+// strain list (newkmer_10nx.cpp:951-971): only its presence is observable ("narin <name>")
+bool strain_list_present(const std::string &path);
+
+struct ProbeSet {
+    std::vector<uint64_t> keys;    // forward keys in file order (process_kmer, :619-661)
+    std::vector<uint32_t> targets;
+    long long lines_parsed = 0;    // tct, printed as "<n> kmers loaded" (:701,:989)
+};
+// process_kmergz (newkmer_10nx.cpp:663-712).  Throws Fatal{255} on gz errors / over-long lines.
+ProbeSet load_probes_gz(const std::string &path, int k);
+
+// ---------------------------------------------------------------- reads
+// process_qual (newkmer_10nx.cpp:714-760).  returns true when process_read would be called.
+// Throws Fatal{134} where qual.at() would throw (quality shorter than sequence).
+bool trim_read(const std::string &seq, const std::string &qual, int k, int &start, int &stop);
+
+// Lines of a (gz or plain) text file under the rules of process_fqgz (newkmer_10nx.cpp:762-816):
+// split at '\n', one trailing '\r' removed, empty lines skipped by the caller, the unterminated
+// last line dropped, a line of 16384 bytes or more is fatal (exit 255).
+class GzLines {
+public:
+    explicit GzLines(const std::string &path);
+    ~GzLines();
+    bool next(const char *&line, size_t &len); // false at end of file
+    void close();                               // throws Fatal{255} "failed gzclose"
+private:
+    void *gz_ = nullptr;
+    std::vector<char> buf_;
+    size_t pos_ = 0, end_ = 0;
+    bool eof_ = false;
+    bool fill();
+};
+
+struct ReadBatch {
+    std::vector<uint8_t> bases;     // whole sequence lines, concatenated
+    std::vector<uint64_t> offsets;  // n+1
+    std::vector<int32_t> start, stop;
+    std::vector<std::string> acc;   // header lines (with the leading '@'), for _reads.txt
+    size_t size() const { return start.size(); }
+    void clear() { bases.clear(); offsets.assign(1, 0); start.clear(); stop.clear(); acc.clear(); }
+};
+
+// Streams one FASTQ file as batches of trimmed reads.  fill() appends up to max_reads reads that
+// survive process_qual to `out` (which it clears first); returns false when the file is exhausted
+// and nothing was appended.
+class FastqStream {
+public:
+    FastqStream(const std::string &path, int k);
+    bool fill(ReadBatch &out, size_t max_reads);
+    void close() { lines_.close(); }
+private:
+    GzLines lines_;
+    int k_;
+    int mod4_ = 0;
+    std::string seq_, acc_;
+};
+
+// ---------------------------------------------------------------- outputs
+// <prefix>_result.txt: "i,gcount[i],ucount[i]\n" for every target (newkmer_10nx.cpp:1040-1043)
+void write_result(const std::string &path, const std::vector<int64_t> &gcount, const std::vector<int64_t> &ucount);
+
+// _reads.txt saver (newkmer_10nx.cpp:608-612): the first 12 reads of every target > 1, file order
+class ReadSaver {
+public:
+    ReadSaver(const std::string &path, int ntar);
+    ~ReadSaver();
+    void add_batch(const ReadBatch &b, const std::vector<uint32_t> &final_targ);
+private:
+    FILE *f_ = nullptr;
+    std::vector<int64_t> seen_; // gcount as the reference sees it at that point of the file
+};
+
+} // namespace kidhost

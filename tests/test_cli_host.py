@@ -1,0 +1,185 @@
+"""Host stages of the nk10 program (database text loaders, FASTQ reader, trimming) on the
+CPU via `nk10 --dry-run`, against the oracle and the reference's golden run; and, on a GPU,
+the whole program against the files the compiled reference wrote."""
+import filecmp
+import gzip
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import K, ob, synth
+from kmer_id_amd import _build
+
+
+def write_tree(path, parent, eol="\r\n"):
+    with open(path, "w", newline="") as fh:
+        for y, x in enumerate(parent.tolist()):
+            if y >= 2 and x != 1:
+                fh.write("%d\t%d%s" % (x, y, eol))
+
+
+def make_db_dir(cwd, scale, extra_probe_text=b""):
+    parent, cnt = synth.load_taxonomy("bact10")
+    cum = synth.cumulative(synth.scaled_counts(cnt, scale))
+    keys, targets = synth.db_keys(cum, K)
+    os.makedirs(os.path.join(cwd, "bact10"), exist_ok=True)
+    write_tree(os.path.join(cwd, "bact10", "btree_10.txt"), parent)
+    with open(os.path.join(cwd, "bact10", "bData10.txt"), "w") as fh:
+        fh.write("4\tCP000828\r\n")
+    p = os.path.join(cwd, "bact10", "probes10.txt.gz")
+    synth.write_probes_gz(p, keys, targets, K)
+    if extra_probe_text:
+        raw = gzip.open(p).read() + extra_probe_text
+        with gzip.open(p, "wb") as fh:
+            fh.write(raw)
+    return parent, cum, keys, targets
+
+
+@pytest.fixture(scope="module")
+def nk10():
+    return _build.build_cli()
+
+
+def parse_dry(path):
+    sec, parent, probes, files = None, {}, [], {}
+    hdr = {}
+    for line in open(path, encoding="latin-1"):
+        line = line.rstrip("\n")
+        if line.startswith("PARENT "):
+            sec = "parent"; hdr["ntar"] = int(line.split()[1]); continue
+        if line.startswith("PROBES "):
+            sec = "probes"; hdr["nkeys"] = int(line.split()[1]); hdr["lines"] = int(line.split()[2]); continue
+        if line.startswith("FILE "):
+            sec = line[5:]; files[sec] = []; continue
+        if sec == "parent":
+            a, b = line.split(); parent[int(a)] = int(b)
+        elif sec == "probes":
+            a, b = line.split(); probes.append((int(a), int(b)))
+        else:
+            acc, st, sp, ln = line.rsplit("\t", 3)
+            files[sec].append((acc, int(st), int(sp), int(ln)))
+    return hdr, parent, probes, files
+
+
+def test_dry_run_host_stages(nk10, gold_dir, tmp_path, kat):
+    src = os.path.join(gold_dir, "e2e_small")
+    cwd = str(tmp_path)
+    # the KAT probes text carries every parser quirk (CRLF, blank, garbage, long, lower case, tail)
+    quirks = gzip.decompress(bytes(kat["probes_gz"]))
+    parent, cum, keys, targets = make_db_dir(cwd, 2e-4, extra_probe_text=quirks)
+    fq = os.path.join(cwd, "fq")
+    os.makedirs(fq)
+    for f in os.listdir(src):
+        if f.endswith(".fastq.gz"):
+            shutil.copy(os.path.join(src, f), fq)
+    dump = os.path.join(cwd, "dry.txt")
+    subprocess.run([nk10, fq + "/", "--dry-run", dump], cwd=cwd, check=True, stdout=subprocess.PIPE)
+    hdr, par, probes, files = parse_dry(dump)
+    # taxonomy
+    exp_par = {i: int(p) for i, p in enumerate(parent.tolist()) if p != 1}
+    assert par == exp_par and hdr["ntar"] == 5982
+    # probes: the oracle's own parser must accept the same number of lines and answer the same lookups
+    odb = ob.OracleDB(parent.size, K, 20, parent=parent)
+    assert odb.load_probes_gz(os.path.join(cwd, "bact10", "probes10.txt.gz")) == hdr["lines"]
+    assert odb.lib.ko_db_size(odb.h) == hdr["nkeys"] == len(probes)
+    pk = np.array([p[0] for p in probes], np.uint64); pt = np.array([p[1] for p in probes], np.uint32)
+    assert np.array_equal(pk[:keys.size], keys) and np.array_equal(pt[:keys.size], targets)
+    odb2 = ob.OracleDB(parent.size, K, 20, parent=parent)
+    odb2.add(pk, pt)
+    q = np.concatenate([pk, kat["lookup_in"]])
+    assert np.array_equal(odb.get(q), odb2.get(q))
+    # reads: the same records with the same (start, stop) as the oracle's reader + process_qual
+    for name, recs in files.items():
+        raw = gzip.open(os.path.join(fq, name)).read()
+        lines = raw.split(b"\n")[:-1]
+        lines = [l[:-1] if l.endswith(b"\r") else l for l in lines]
+        lines = [l for l in lines if l]
+        exp = []
+        for i in range(0, len(lines) - 3, 4):
+            acc, seq, qual = lines[i], lines[i + 1], lines[i + 3]
+            called, st, sp = ob.process_qual(qual, len(seq), K)
+            assert called >= 0
+            if called:
+                exp.append((acc.decode("latin-1"), st, sp, len(seq)))
+        assert recs == exp, name
+    assert sum(len(v) for v in files.values()) > 700
+
+
+def test_fatal_inputs_exit_codes(nk10, tmp_path):
+    cwd = str(tmp_path)
+    make_db_dir(cwd, 2e-5)
+    fq = os.path.join(cwd, "fq"); os.makedirs(fq)
+    dump = os.path.join(cwd, "dry.txt")
+    # a 16384-byte line is fatal with exit code 255 (newkmer_10nx.cpp:773), 16383 bytes is fine
+    def fq_with_line(n):
+        with gzip.open(os.path.join(fq, "L_R1_tr.fastq.gz"), "wb") as fh:
+            fh.write(b"@a\n" + b"A" * n + b"\n+\n" + b"I" * n + b"\n")
+        with gzip.open(os.path.join(fq, "L_R2_tr.fastq.gz"), "wb") as fh:
+            fh.write(b"@b\nACGT\n+\nIIII\n")
+        return subprocess.run([nk10, fq + "/", "--dry-run", dump], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert fq_with_line(16383).returncode == 0
+    r = fq_with_line(16384)
+    assert r.returncode == 255 and b"Buffer to small" in r.stderr
+    # quality shorter than sequence: the reference dies in std::string::at (abort -> 134)
+    with gzip.open(os.path.join(fq, "L_R1_tr.fastq.gz"), "wb") as fh:
+        fh.write(b"@a\nACGTACGT\n+\nIIII\n")
+    r = subprocess.run([nk10, fq + "/", "--dry-run", dump], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 134
+    # missing R2 file: gzopen fails -> exit 255
+    os.remove(os.path.join(fq, "L_R2_tr.fastq.gz"))
+    with gzip.open(os.path.join(fq, "L_R1_tr.fastq.gz"), "wb") as fh:
+        fh.write(b"@a\nACGTACGT\n+\nIIIIIIII\n")
+    r = subprocess.run([nk10, fq + "/", "--dry-run", dump], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 255
+    # no arguments: usage
+    assert subprocess.run([nk10], stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode == 2
+
+
+# ------------------------------------------------------------------ whole program on the GPU
+@pytest.mark.gpu
+def test_nk10_end_to_end_small(nk10, gold_dir, tmp_path):
+    src = os.path.join(gold_dir, "e2e_small")
+    params = json.load(open(os.path.join(src, "params.json")))
+    cwd = str(tmp_path)
+    make_db_dir(cwd, params["scale"])
+    fq = os.path.join(cwd, "fq"); os.makedirs(fq)
+    for f in os.listdir(src):
+        if f.endswith(".fastq.gz"):
+            shutil.copy(os.path.join(src, f), fq)
+    r = subprocess.run([nk10, fq + "/", "--log2-slots", "22", "--batch-reads", "97"], cwd=cwd, stdout=subprocess.PIPE, check=True)
+    for prefix in ("S1", "S2"):
+        for suffix in ("_result.txt", "_reads.txt"):
+            assert filecmp.cmp(os.path.join(fq, prefix + suffix), os.path.join(src, prefix + suffix), shallow=False), prefix + suffix
+    # stdout: same lines as the reference (sample order is readdir order on both sides)
+    got = r.stdout.decode().replace(fq + "/", "<DIR>").splitlines()
+    exp = open(os.path.join(src, "stdout.txt")).read().splitlines()
+    assert sorted(got) == sorted(exp)
+    assert got[:3] == exp[:3]
+
+
+@pytest.mark.gpu
+def test_nk10_end_to_end_seeded(nk10, gold_dir, tmp_path):
+    params = json.load(open(os.path.join(gold_dir, "e2e_seeded.json")))
+    cwd = str(tmp_path)
+    parent, cum, keys, targets = make_db_dir(cwd, params["scale"])
+    fq = os.path.join(cwd, "fq"); os.makedirs(fq)
+    n, L = params["n_pairs"], params["read_len"]
+    synth.write_fastq_gz(os.path.join(fq, "big_R1_tr.fastq.gz"), synth.reads(cum, parent, n, L, K, r0=0), synth.qualities(n, L, r0=0), L, mate=1)
+    synth.write_fastq_gz(os.path.join(fq, "big_R2_tr.fastq.gz"), synth.reads(cum, parent, n, L, K, r0=n), synth.qualities(n, L, r0=n), L, mate=2)
+    subprocess.run([nk10, fq + "/", "--log2-slots", "22", "--batch-reads", "5000"], cwd=cwd, stdout=subprocess.PIPE, check=True)
+    res = open(os.path.join(fq, "big_result.txt"), "rb").read()
+    assert res == gzip.open(os.path.join(gold_dir, "e2e_seeded_result.txt.gz")).read()
+    assert hashlib.sha256(open(os.path.join(fq, "big_reads.txt"), "rb").read()).hexdigest() == params["reads_sha256"]
+
+
+@pytest.mark.gpu
+def test_nk10_unreadable_directory(nk10, tmp_path):
+    cwd = str(tmp_path)
+    make_db_dir(cwd, 2e-5)
+    r = subprocess.run([nk10, os.path.join(cwd, "nope") + "/", "--log2-slots", "16"], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"hosed" in r.stdout
