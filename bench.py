@@ -43,7 +43,7 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def build_db(device, scale, log2_slots, keep_host_copy):
+def build_db(device, scale, log2_slots, keep_host_copy, flags=0, keep_device_keys=False):
     """bact10-synth: keys generated on the device, table built on the device."""
     parent, cnt = synth.load_taxonomy("bact10")
     cum = synth.cumulative(synth.scaled_counts(cnt, scale))
@@ -56,14 +56,16 @@ def build_db(device, scale, log2_slots, keep_host_copy):
                                                         C.c_void_p(d_keys.data_ptr()), C.c_void_p(d_targets.data_ptr()),
                                                         device.index))
     t0 = time.time()
-    db = KmerDB.from_device(d_keys.data_ptr(), d_targets.data_ptr(), n, parent, k=K, log2_slots=log2_slots, device=device.index)
+    db = KmerDB.from_device(d_keys.data_ptr(), d_targets.data_ptr(), n, parent, k=K, log2_slots=log2_slots, flags=flags,
+                            device=device.index)
     build_s = time.time() - t0
     host = None
     if keep_host_copy:
         host = (d_keys.cpu().numpy().view(np.uint64), d_targets.cpu().numpy().view(np.uint32))
+    dev = (d_keys, d_targets, n) if keep_device_keys else None
     del d_keys, d_targets
     torch.cuda.empty_cache()
-    return db, parent, cum, build_s, host
+    return db, parent, cum, build_s, host, dev
 
 
 def gen_reads(device, cum, parent, r0, n_reads):
@@ -112,6 +114,11 @@ def main():
     ap.add_argument("--cpu-reads", type=int, default=300_000, help="reads of the CPU baseline sample (0 = skip)")
     ap.add_argument("--batches", type=int, default=4, help="distinct resident read batches cycled over the steps")
     ap.add_argument("--gather", type=int, default=1, help="also measure the random 16-byte gather ceiling")
+    ap.add_argument("--geometry", choices=["minloc", "ref"], default="minloc",
+                    help="table placement: minimizer-localised (default) or the reference's fmix64/triangular one")
+    ap.add_argument("--xcheck", type=int, default=1,
+                    help="classify the first batch on a second table built with the reference's geometry too: "
+                         "full-size parity of the two placements + the reference-geometry probe count")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,7 +138,9 @@ def main():
     n_reads = 2 * args.pairs  # R1 + R2, classified independently (newkmer_10nx.cpp:1029-1031)
     want_cpu = (rank == 0 and world == 1 and args.cpu_reads > 0)
     log("building bact10-synth DB (scale %g, 2^%d cells) ..." % (args.scale, args.log2_slots))
-    db, parent, cum, build_s, host_keys = build_db(device, args.scale, args.log2_slots, want_cpu)
+    flags = kmer_id_amd.KID_FLAG_REF_GEOMETRY if args.geometry == "ref" else 0
+    want_x = bool(args.xcheck) and args.geometry == "minloc" and rank == 0
+    db, parent, cum, build_s, host_keys, dev_keys = build_db(device, args.scale, args.log2_slots, want_cpu, flags, want_x)
     info = db.info
     log("DB: %d entries, %d cells occupied, table %.1f GiB, GPU build %.2f s" % (info.n_entries, info.n_occupied,
                                                                                  info.table_bytes / 2**30, build_s))
@@ -145,6 +154,32 @@ def main():
         sample.classify_fixed_device(batches[i % nb].data_ptr(), READ_LEN, n_reads, d_out=out_final.data_ptr(),
                                      stream=stream.cuda_stream)
 
+    # full-size cross-check (untimed): the same batch through a table with the reference's cell
+    # placement must give the same per-read targets and counters; its probe count is the
+    # "algorithmic" number of cells the reference's own table would have read.
+    xcheck = None
+    ref_probes_per_lookup = None
+    if want_x:
+        d_keys, d_targets, n_keys = dev_keys
+        rdb = KmerDB.from_device(d_keys.data_ptr(), d_targets.data_ptr(), n_keys, parent, k=K, log2_slots=args.log2_slots,
+                                 flags=kmer_id_amd.KID_FLAG_REF_GEOMETRY, device=device.index)
+        del d_keys, d_targets, dev_keys
+        rs = rdb.sample()
+        out_ref = torch.empty(n_reads, dtype=torch.int32, device=device)
+        rs.classify_fixed_device(batches[0].data_ptr(), READ_LEN, n_reads, d_out=out_ref.data_ptr(), stream=stream.cuda_stream)
+        step(0)
+        torch.cuda.synchronize(device)
+        g1, u1 = sample.end()
+        g2, u2 = rs.end()
+        st_ref = rs.stats()
+        xcheck = bool(torch.equal(out_ref, out_final) and np.array_equal(g1, g2) and np.array_equal(u1, u2))
+        ref_probes_per_lookup = st_ref["probes"] / max(st_ref["lookups"], 1)
+        log("cross-check vs reference geometry on %d reads: %s (reference geometry reads %.4f cells per lookup)" % (
+            n_reads, "identical" if xcheck else "MISMATCH", ref_probes_per_lookup))
+        rs.close(); rdb.close(); del out_ref
+        torch.cuda.empty_cache()
+        if not xcheck:
+            raise SystemExit("minimizer-localised and reference geometries disagree")
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(device)
@@ -180,7 +215,14 @@ def main():
     assert total_reads == args.steps * n_reads, (total_reads, args.steps * n_reads)
     assert int(g.sum()) == args.steps * n_reads * world, "gcount does not add up to the reads processed"
     kern_s = sum(kernel_ms) / 1e3
-    probes_per_launch = st["probes"] / args.steps
+    # algorithmic bytes: 16 B per table cell the REFERENCE's table geometry reads for
+    # these lookups (counted exactly on the reference-geometry table above), whatever our own
+    # placement needs; without the cross-check, our own cell count stands in.
+    cells_read_per_launch = st["probes"] / args.steps
+    if ref_probes_per_lookup is not None:
+        probes_per_launch = ref_probes_per_lookup * st["lookups"] / args.steps
+    else:
+        probes_per_launch = cells_read_per_launch
     avg_kernel_s = kern_s / args.steps
     achieved = probes_per_launch * 16 / avg_kernel_s / 1e9
 
@@ -228,6 +270,8 @@ def main():
                          "kernel": "kid_classify_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": probes_per_launch * 16,
                          "lookups_per_launch": st["lookups"] / args.steps, "probes_per_launch": probes_per_launch,
+                         "cells_read_per_launch": cells_read_per_launch, "geometry": args.geometry,
+                         "fullsize_parity_vs_reference_geometry": xcheck,
                          "lookups_per_s": st["lookups"] / kern_s, "kernel_only_pairs_per_s": args.pairs / avg_kernel_s,
                          **extra},
             "cpu_baseline": cpu,

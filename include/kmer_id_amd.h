@@ -45,6 +45,9 @@ typedef enum kid_status {
 #define KID_FLAG_U_IS_T 1u    /* U/u is read as T: kmer_read_vf6.cpp:496-500,521-525 */
 #define KID_FLAG_HOST_BUILD 2u /* build the table on the host with the reference's sequential insert
                                   order (exact cell geometry).  Implied when max_probes > 0. */
+#define KID_FLAG_REF_GEOMETRY 4u /* GPU build, but with the reference's cell placement (fmix64 +
+                                  triangular probing) instead of the minimizer-localised one.  Lookup
+                                  results are the same either way; only speed differs. */
 
 typedef struct kid_db kid_db;         /* hash table + taxonomy, resident in one GPU's HBM */
 typedef struct kid_sample kid_sample; /* per-sample counters: gcount, seen-bitmap (-> ucount) */
@@ -58,6 +61,8 @@ typedef struct kid_db_info {
     int32_t device;
     int32_t tree_depth;  /* deepest node (root = 0) */
     int32_t host_built;  /* 1 if the sequential host builder produced the table */
+    int32_t geometry;    /* 0 = reference placement, 1 = minimizer-localised placement */
+    int32_t reserved_;
     uint64_t n_entries;  /* entries handed to the builder */
     uint64_t n_occupied; /* cells with value != 0 */
     uint64_t table_bytes;

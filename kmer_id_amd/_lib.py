@@ -22,6 +22,7 @@ class KidDbInfo(C.Structure):
     _fields_ = [
         ("ntar", C.c_int32), ("k", C.c_int32), ("log2_slots", C.c_int32), ("max_probes", C.c_int32),
         ("flags", C.c_uint32), ("device", C.c_int32), ("tree_depth", C.c_int32), ("host_built", C.c_int32),
+        ("geometry", C.c_int32), ("reserved_", C.c_int32),
         ("n_entries", C.c_uint64), ("n_occupied", C.c_uint64), ("table_bytes", C.c_uint64),
     ]
 
@@ -72,6 +73,7 @@ PROTOTYPES = {
 
 KID_FLAG_U_IS_T = 1
 KID_FLAG_HOST_BUILD = 2
+KID_FLAG_REF_GEOMETRY = 4
 
 _lib = None
 

@@ -249,6 +249,9 @@ static int kid_db_build_common(const uint64_t *h_keys, const uint32_t *h_targets
 
     uint64_t n_occupied = 0;
     const bool host_build = (max_probes > 0) || (flags & KID_FLAG_HOST_BUILD);
+    // minimizer-localised placement needs an unbounded probe loop (results must not depend on the
+    // cell geometry) and a window of 16 m-mers with 8 <= m <= 16
+    const uint32_t minloc = (!host_build && !(flags & KID_FLAG_REF_GEOMETRY) && k >= 23) ? 1u : 0u;
     if (host_build) {
         std::vector<uint64_t> hk;
         std::vector<uint32_t> ht;
@@ -287,9 +290,9 @@ static int kid_db_build_common(const uint64_t *h_keys, const uint32_t *h_targets
             KID_DB_HIP(hipMemset(d_occ, 0, 16));
             const int grid = kid_grid_for(n, 256, db->num_cu * 16);
             hipLaunchKernelGGL(kid_build_insert_kernel, dim3(grid), dim3(256), 0, 0, db->table, (uint32_t)(nslots - 1), dkc,
-                               dtc, n, (uint32_t)ntar, d_occ);
+                               dtc, n, (uint32_t)ntar, d_occ, k, minloc);
             hipLaunchKernelGGL(kid_build_firstwins_kernel, dim3(grid), dim3(256), 0, 0, db->table, (uint32_t)(nslots - 1),
-                               dkc, dtc, n);
+                               dkc, dtc, n, k, minloc);
             hipError_t e = hipDeviceSynchronize();
             unsigned long long occ[2] = {0, 0};
             if (e == hipSuccess) e = hipMemcpy(occ, d_occ, 16, hipMemcpyDeviceToHost);
@@ -309,6 +312,8 @@ static int kid_db_build_common(const uint64_t *h_keys, const uint32_t *h_targets
     db->d.max_probes = (uint32_t)max_probes;
     db->d.k = k;
     db->d.u_is_t = (flags & KID_FLAG_U_IS_T) ? 1u : 0u;
+    db->d.minloc = minloc;
+    db->info.geometry = (int32_t)minloc;
     db->d.rows = db->rows;
     db->d.parent = db->parent;
     db->d.depth = db->depth;
@@ -478,10 +483,17 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, hipStream_t str
     const int grid = kid_grid_for(b.n, wpb, db->num_cu * 4);
     KidSampleDev sd{s->gcount, s->seen, s->stats};
     const bool rows = db->rows != nullptr;
-    if (rows && hist) hipLaunchKernelGGL((kid_classify_kernel<2, true, true>), dim3(grid), dim3(block), lds, stream, db->d, b, sd, hist_words);
-    else if (rows) hipLaunchKernelGGL((kid_classify_kernel<2, true, false>), dim3(grid), dim3(block), lds, stream, db->d, b, sd, hist_words);
-    else if (hist) hipLaunchKernelGGL((kid_classify_kernel<2, false, true>), dim3(grid), dim3(block), lds, stream, db->d, b, sd, hist_words);
-    else hipLaunchKernelGGL((kid_classify_kernel<2, false, false>), dim3(grid), dim3(block), lds, stream, db->d, b, sd, hist_words);
+#define KID_LAUNCH(R, H, M) hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M>), dim3(grid), dim3(block), lds, stream, db->d, b, sd, hist_words)
+    const bool ml = db->d.minloc != 0;
+    if (rows && hist && ml) KID_LAUNCH(true, true, true);
+    else if (rows && hist) KID_LAUNCH(true, true, false);
+    else if (rows && ml) KID_LAUNCH(true, false, true);
+    else if (rows) KID_LAUNCH(true, false, false);
+    else if (hist && ml) KID_LAUNCH(false, true, true);
+    else if (hist) KID_LAUNCH(false, true, false);
+    else if (ml) KID_LAUNCH(false, false, true);
+    else KID_LAUNCH(false, false, false);
+#undef KID_LAUNCH
     KID_HIP(hipGetLastError());
     return KID_OK;
 }

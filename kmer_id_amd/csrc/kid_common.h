@@ -67,6 +67,68 @@ KID_HD int kid_base_code(uint8_t c, bool u_is_t)
     }
 }
 
+// ---------------------------------------------------------------- minimizer-localised table geometry
+// The GPU-native table keeps the reference's cells and its first-insert-wins lookup results but
+// places a key by the MINIMIZER of its k-mer: all k-mers that share their smallest (hashed,
+// strand-symmetric) m-mer, m = k - 15, live in one 128-byte line of 8 cells.  Consecutive
+// k-mers of a read share their minimizer for ~8.5 positions, so the lanes of a wavefront
+// (consecutive read positions) hit ~8 distinct lines per 64 lookups instead of 64 -- the
+// lookups coalesce.  Only legal where the probe loop is unbounded (newkmer_10nx, kmer_read_vf6):
+// there the answer depends on the key -> first target map alone, not on where cells sit.
+#define KID_MIN_W 16      // m-mers per k-mer window
+#define KID_LINE_LOG2 3   // cells per line = 8 (128 bytes)
+
+KID_HD uint32_t kid_rev2_32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    x = __brev(x);
+#else
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+    x = (x >> 16) | (x << 16);
+#endif
+    return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+}
+
+// hash of the canonical form of the m-mer f (2m bits, m <= 16); identical for an m-mer and its
+// reverse complement
+KID_HD uint32_t kid_mmer_hash(uint32_t f, int m)
+{
+    const uint32_t r = (~kid_rev2_32(f)) >> (32 - 2 * m);
+    uint32_t h = f < r ? f : r;
+    h *= 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    h ^= h >> 13;
+    return h;
+}
+
+// minimizer of a whole k-mer given as its 2k-bit forward key (brute force: table build, unit lookups)
+KID_HD uint32_t kid_minimizer_of_key(uint64_t keyF, int k)
+{
+    const int m = k - (KID_MIN_W - 1);
+    const uint32_t mm = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+    uint32_t g = 0xFFFFFFFFu;
+    for (int j = 0; j < KID_MIN_W; j++) {
+        const uint32_t h = kid_mmer_hash((uint32_t)(keyF >> (2 * (KID_MIN_W - 1 - j))) & mm, m);
+        g = h < g ? h : g;
+    }
+    return g;
+}
+
+// first cell of the probe sequence: line chosen by the minimizer, cell in the line by the key
+KID_HD uint32_t kid_minloc_home(uint32_t g, uint64_t key, uint32_t slot_mask)
+{
+    uint32_t l = g * 0xC2B2AE3Du;
+    l ^= l >> 16;
+    l *= 0x27D4EB2Fu;
+    l ^= l >> 15;
+    const uint32_t sub = ((uint32_t)key * 0x9E3779B1u) >> (32 - KID_LINE_LOG2);
+    return ((l << KID_LINE_LOG2) | sub) & slot_mask;
+}
+
 // ---------------------------------------------------------------- synthetic data
 KID_HD uint64_t kid_splitmix64(uint64_t x)
 {

@@ -48,6 +48,7 @@ struct KidDevDb {
     uint32_t max_probes;
     int k;
     uint32_t u_is_t;
+    uint32_t minloc; // 1: minimizer-localised geometry (kid_common.h), 0: the reference's fmix64 + triangular probing
     const uint4 *rows; // null when the tree does not fit the row encoding
     const int32_t *parent;
     const int32_t *depth;
@@ -74,10 +75,22 @@ struct KidSampleDev {
 // Hashtable::getHash, newkmer_10nx.cpp:204-233 (+ probe cap kmer_read_m3.cpp:232)
 __device__ __forceinline__ uint32_t kid_dev_lookup(const KidDevDb &db, uint64_t key, uint32_t &slot, uint32_t &nprobe)
 {
-    const uint64_t hash = kid_fmix64(key);
-    uint64_t reprobe = 0;
     uint32_t i = 0, res = 0;
     slot = 0;
+    if (db.minloc) {
+        const uint32_t home = kid_minloc_home(kid_minimizer_of_key(key, db.k), key, db.slot_mask);
+        for (;;) { // linear probing; the table always keeps >= 32 empty cells
+            const uint32_t idx = (home + i) & db.slot_mask;
+            ++i;
+            const uint4 c = db.table[idx];
+            if (c.z == 0) break;
+            if (c.x == (uint32_t)key && c.y == (uint32_t)(key >> 32)) { res = c.z; slot = idx; break; }
+        }
+        nprobe = i;
+        return res;
+    }
+    const uint64_t hash = kid_fmix64(key);
+    uint64_t reprobe = 0;
     do {
         const uint32_t idx = ((uint32_t)hash + (uint32_t)reprobe) & db.slot_mask;
         reprobe += ++i;
@@ -87,6 +100,28 @@ __device__ __forceinline__ uint32_t kid_dev_lookup(const KidDevDb &db, uint64_t 
     } while (reprobe < db.nslots && (db.max_probes == 0 || i < db.max_probes));
     nprobe = i;
     return res;
+}
+
+// ------------------------------------------------------------------ sliding-window minimum over a wavefront
+// 16-lane DPP rows double as the blocks of the van Herk / Gil-Werman scheme: with P = prefix
+// minimum and S = suffix minimum inside each row, min(a[p..p+15]) = min(S[p], P[p+15]).
+__device__ __forceinline__ uint32_t kid_row_prefix_min(uint32_t x)
+{
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x111, 0xF, 0xF, false); x = x < t ? x : t; // row_shr:1
+    t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x112, 0xF, 0xF, false); x = x < t ? x : t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x114, 0xF, 0xF, false); x = x < t ? x : t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x118, 0xF, 0xF, false); x = x < t ? x : t;
+    return x;
+}
+__device__ __forceinline__ uint32_t kid_row_suffix_min(uint32_t x)
+{
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x101, 0xF, 0xF, false); x = x < t ? x : t; // row_shl:1
+    t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x102, 0xF, 0xF, false); x = x < t ? x : t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x104, 0xF, 0xF, false); x = x < t ? x : t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x108, 0xF, 0xF, false); x = x < t ? x : t;
+    return x;
 }
 
 // ------------------------------------------------------------------ taxonomy
@@ -159,13 +194,15 @@ __device__ __forceinline__ void kid_pack16(const uint4 v, const uint32_t u_is_t,
 //      packs it to 2 bits/base into the wave's private LDS strip;
 //   2. lane i extracts the k-mer window starting at base i from LDS with two
 //      shifts (no serial rolling), derives the reverse complement with a bit
-//      reversal, takes min(), hashes and probes the table in HBM -- U windows per
-//      lane in flight at once;
-//   3. hits are folded with msca in read-position order (the fold is not
+//      reversal and takes min(); with the minimizer-localised geometry the wave
+//      also computes the sliding-window minimum of the hashed m-mers (DPP row scans
+//      + one cross-lane fetch), which selects the table line;
+//   3. the table is probed in HBM -- U windows per lane in flight at once;
+//   4. hits are folded with msca in read-position order (the fold is not
 //      associative: newkmer_10nx.cpp:588-595) on wave-uniform registers;
-//   4. hit cells are marked in the sample's seen-bitmap (ucount, :596-603).
+//   5. hit cells are marked in the sample's seen-bitmap (ucount, :596-603).
 // gcount is accumulated in an LDS histogram per workgroup and flushed once.
-template <int U, bool ROWS, bool HIST>
+template <int U, bool ROWS, bool HIST, bool MINLOC>
 __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db, const KidBatch b, const KidSampleDev s,
                                                             const uint32_t hist_words)
 {
@@ -184,6 +221,7 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
     }
 
     const int k = db.k;
+    const int mlen = k - (KID_MIN_W - 1);
     const uint64_t gw = (uint64_t)blockIdx.x * wpb + wib;
     const uint64_t nw = (uint64_t)gridDim.x * wpb;
     uint64_t n_lookups = 0, n_probes = 0; // per lane
@@ -237,10 +275,10 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-            // ---- 2..4 per group of U*64 windows
+            // ---- 2..5 per group of U*64 windows
             for (uint32_t t0 = 0; t0 < segk; t0 += U * 64u) {
                 uint64_t key[U];
-                uint32_t hlo[U];
+                uint32_t hlo[U]; // first cell of the probe sequence
                 bool act[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -254,49 +292,42 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
                     const uint64_t im = (((uint64_t)IM[(p >> 5) + 1] << 32) | IM[p >> 5]) >> (p & 31u);
                     const bool valid = (i < segk) && ((im & ((1ull << k) - 1ull)) == 0);
                     key[u] = kid_canonical(keyF, k);
-                    hlo[u] = (uint32_t)kid_fmix64(key[u]);
+                    if (!MINLOC) hlo[u] = (uint32_t)kid_fmix64(key[u]) & db.slot_mask;
                     act[u] = valid;
                     n_lookups += valid ? 1u : 0u;
+                }
+                if (MINLOC) {
+                    // hashed canonical m-mers at the U*64 + 15 start positions of this group ...
+                    uint32_t P[U + 1], S[U];
+                    const uint32_t pmax = sh + nb - (uint32_t)mlen; // last m-mer start inside the segment
+#pragma unroll
+                    for (int j = 0; j <= U; j++) {
+                        uint32_t p = sh + t0 + (uint32_t)j * 64u + lane;
+                        p = p < pmax ? p : pmax; // positions past the end never belong to a valid k-mer
+                        const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
+                        const uint64_t A = ((uint64_t)W[w0] << 32) | W[w0 + 1];
+                        const uint32_t f = (uint32_t)((A << o2) >> (64 - 2 * mlen));
+                        const uint32_t h = kid_mmer_hash(f, mlen);
+                        P[j] = kid_row_prefix_min(h);
+                        if (j < U) S[j] = kid_row_suffix_min(h);
+                    }
+                    // ... and their minimum over every window of 16: min(a[p..p+15]) = min(S[p], P[p+15])
+                    const uint32_t src = (lane + 15u) & 63u;
+                    uint32_t nxt = (uint32_t)__shfl((int)P[0], (int)src);
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint32_t same = nxt;
+                        nxt = (uint32_t)__shfl((int)P[u + 1], (int)src);
+                        const uint32_t pn = (lane + 15u < 64u) ? same : nxt;
+                        const uint32_t g = S[u] < pn ? S[u] : pn;
+                        hlo[u] = kid_minloc_home(g, key[u], db.slot_mask);
+                    }
                 }
                 uint32_t tgt[U], slot[U], step[U];
                 uint64_t rp[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) { tgt[u] = 0; slot[u] = 0; step[u] = 0; rp[u] = 0; }
                 bool any = false;
-#if KID_PAIR
-                // probes 1 and 2 (cells h and h+1, the same 64-byte sector 3 times out of 4) are
-                // fetched together: one memory round trip settles ~99 % of the lookups
-                {
-                    uint4 c0[U], c1[U];
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        c0[u] = make_uint4(0, 0, 0, 0);
-                        c1[u] = make_uint4(0, 0, 0, 0);
-                        if (act[u]) {
-                            c0[u] = kid_load_cell(db.table, hlo[u] & db.slot_mask);
-                            c1[u] = kid_load_cell(db.table, (hlo[u] + 1u) & db.slot_mask);
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        if (act[u]) {
-                            const uint32_t klo = (uint32_t)key[u], khi = (uint32_t)(key[u] >> 32);
-                            step[u] = 1;
-                            rp[u] = 1;
-                            if (c0[u].z == 0) act[u] = false;
-                            else if (c0[u].x == klo && c0[u].y == khi) { tgt[u] = c0[u].z; slot[u] = hlo[u] & db.slot_mask; act[u] = false; }
-                            else if (db.max_probes == 1) act[u] = false;
-                            else {
-                                step[u] = 2;
-                                rp[u] = 3;
-                                if (c1[u].z == 0) act[u] = false;
-                                else if (c1[u].x == klo && c1[u].y == khi) { tgt[u] = c1[u].z; slot[u] = (hlo[u] + 1u) & db.slot_mask; act[u] = false; }
-                                else if (db.max_probes == 2) act[u] = false;
-                            }
-                        }
-                    }
-                }
-#endif
 #pragma unroll
                 for (int u = 0; u < U; u++) any |= act[u];
                 while (any) {
@@ -313,11 +344,11 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
                     for (int u = 0; u < U; u++) {
                         if (act[u]) {
                             step[u]++;
-                            rp[u] += step[u];
+                            rp[u] += MINLOC ? 1u : step[u]; // linear inside/after the line vs the reference's triangular steps
                             if (c[u].z == 0) act[u] = false;
                             else if (c[u].x == (uint32_t)key[u] && c[u].y == (uint32_t)(key[u] >> 32)) {
                                 tgt[u] = c[u].z; slot[u] = idx[u]; act[u] = false;
-                            } else if (!(rp[u] < db.nslots) || (db.max_probes != 0 && step[u] >= db.max_probes)) act[u] = false;
+                            } else if (!MINLOC && (!(rp[u] < db.nslots) || (db.max_probes != 0 && step[u] >= db.max_probes))) act[u] = false;
                         }
                         any |= act[u];
                     }
@@ -457,19 +488,26 @@ __global__ void kid_trim_kernel(const uint8_t *quals, const uint64_t *offsets, u
 // word.  Like the reference there is no key comparison: duplicates take
 // separate cells.  Entries with target 0 are skipped: in the reference they
 // leave their cell "empty" (value == 0), i.e. invisible to every lookup.
+// probe sequence shared by both build passes: cell i of key's path in either geometry
+__device__ __forceinline__ uint32_t kid_path_first(uint64_t key, int k, uint32_t minloc, uint32_t slot_mask)
+{
+    return minloc ? kid_minloc_home(kid_minimizer_of_key(key, k), key, slot_mask) : ((uint32_t)kid_fmix64(key) & slot_mask);
+}
+
 __global__ void kid_build_insert_kernel(uint4 *table, uint32_t slot_mask, const uint64_t *keys, const uint32_t *targets,
-                                        uint64_t n, uint32_t ntar, unsigned long long *n_occupied)
+                                        uint64_t n, uint32_t ntar, unsigned long long *n_occupied, int k, uint32_t minloc)
 {
     for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t t = targets[e];
         if (t == 0) continue;
         if (t >= ntar) { atomicAdd(n_occupied + 1, 1ull); continue; } // reported as KID_ERR_TARGET
         const uint64_t key = keys[e];
-        const uint32_t h = (uint32_t)kid_fmix64(key);
+        const uint32_t h = kid_path_first(key, k, minloc, slot_mask);
         uint32_t rp = 0, i = 0;
         for (;;) {
             const uint32_t idx = (h + rp) & slot_mask;
-            rp += ++i;
+            ++i;
+            rp += minloc ? 1u : i;
             uint32_t *ordp = reinterpret_cast<uint32_t *>(table + idx) + 3;
             if (atomicCAS(ordp, 0u, (uint32_t)e + 1u) == 0u) {
                 uint32_t *c = reinterpret_cast<uint32_t *>(table + idx);
@@ -491,16 +529,17 @@ __global__ void kid_build_insert_kernel(uint4 *table, uint32_t slot_mask, const 
 // Key and ordinal words are immutable during this pass; only target words of
 // "first" cells are written, and all writers of one cell write the same value.
 __global__ void kid_build_firstwins_kernel(uint4 *table, uint32_t slot_mask, const uint64_t *keys, const uint32_t *targets,
-                                           uint64_t n)
+                                           uint64_t n, int k, uint32_t minloc)
 {
     for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
         if (targets[e] == 0 || table == nullptr) continue;
         const uint64_t key = keys[e];
-        const uint32_t h = (uint32_t)kid_fmix64(key);
+        const uint32_t h = kid_path_first(key, k, minloc, slot_mask);
         uint32_t rp = 0, i = 0, first_idx = 0, min_ord = 0, copies = 0;
         for (;;) {
             const uint32_t idx = (h + rp) & slot_mask;
-            rp += ++i;
+            ++i;
+            rp += minloc ? 1u : i;
             const uint32_t *c = reinterpret_cast<const uint32_t *>(table + idx);
             const uint32_t ord = c[3];
             if (ord == 0) break;

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import kmer_id_amd
-from kmer_id_amd import KID_FLAG_HOST_BUILD, KID_FLAG_U_IS_T, KmerDB, synth
+from kmer_id_amd import KID_FLAG_HOST_BUILD, KID_FLAG_REF_GEOMETRY, KID_FLAG_U_IS_T, KmerDB, synth
 from helpers import K, concat_reads, ob, oracle_db, parse_probes_text, small_db, unpack_strings
 
 pytestmark = pytest.mark.gpu
@@ -22,12 +22,16 @@ def kat_entries(kat):
     return parent, keys, targets
 
 
-@pytest.fixture(scope="module", params=["gpu_build", "host_build"])
+GEOMETRIES = {"minimizer_localised": 0, "gpu_reference_geometry": KID_FLAG_REF_GEOMETRY, "host_sequential": KID_FLAG_HOST_BUILD}
+
+
+@pytest.fixture(scope="module", params=list(GEOMETRIES))
 def kat_db(request, kat, kat_entries):
     parent, keys, targets = kat_entries
-    flags = KID_FLAG_HOST_BUILD if request.param == "host_build" else 0
+    flags = GEOMETRIES[request.param]
     db = KmerDB(keys, targets, parent, k=K, log2_slots=int(kat["log2_slots"]), flags=flags)
-    assert db.info.host_built == (1 if flags else 0)
+    assert db.info.host_built == (1 if flags == KID_FLAG_HOST_BUILD else 0)
+    assert db.info.geometry == (1 if flags == 0 else 0)
     yield db
     db.close()
 
@@ -123,11 +127,11 @@ def test_process_read_golden(kat, kat_db):
 
 
 # ------------------------------------------------------------------ seeded runs against the oracle
-@pytest.fixture(scope="module")
-def seeded():
+@pytest.fixture(scope="module", params=["minimizer_localised", "gpu_reference_geometry"])
+def seeded(request):
     parent, cum, keys, targets = small_db(1e-3)
     odb = oracle_db(parent, keys, targets, 20)
-    db = KmerDB(keys, targets, parent, k=K, log2_slots=20)
+    db = KmerDB(keys, targets, parent, k=K, log2_slots=20, flags=GEOMETRIES[request.param])
     yield parent, cum, keys, targets, odb, db
     db.close()
 
@@ -308,7 +312,7 @@ def test_u_is_t_flag_vf6(seeded):
         s.close(); db.close()
 
 
-def test_mito_taxonomy_large_ntar_path(seeded):
+def test_mito_taxonomy_large_ntar_path():
     """17227 targets: gcount leaves the LDS histogram for the run-length + global-atomic path"""
     parent, cnt = synth.load_taxonomy("mito")
     cum = synth.cumulative(synth.scaled_counts(cnt, 2e-3))
@@ -405,11 +409,51 @@ def test_duplicate_keys_first_wins_on_gpu_build():
     k3, t3 = k3[perm], t3[perm]
     t3[::17] = 0  # target-0 entries are invisible
     odb = oracle_db(parent, k3, t3, 18)
-    db = KmerDB(k3, t3, parent, k=K, log2_slots=18)
-    assert db.info.host_built == 0
     exp = odb.get(keys)
-    assert np.array_equal(db.lookup(keys), exp)
-    db.close()
+    for flags in (0, KID_FLAG_REF_GEOMETRY):
+        db = KmerDB(k3, t3, parent, k=K, log2_slots=18, flags=flags)
+        assert db.info.host_built == 0
+        assert np.array_equal(db.lookup(keys), exp)
+        db.close()
+
+
+def test_crowded_table_and_heavy_minimizers():
+    """load 0.9 and thousands of k-mers sharing one minimizer (tandem-repeat style keys): long
+    linear-probe runs in the minimizer-localised table, results unchanged"""
+    parent, cum, keys, targets = small_db(2e-4)
+    rng = np.random.default_rng(21)
+    # 3000 keys that all contain the same 15-mer at varying offsets -> few distinct minimizers
+    core = int(rng.integers(0, 1 << 30))
+    fam = []
+    for i in range(3000):
+        off = int(rng.integers(0, 16))
+        left = int(rng.integers(0, 1 << (2 * off))) if off else 0
+        right_bits = 2 * (15 - off)
+        right = int(rng.integers(0, 1 << right_bits)) if right_bits else 0
+        fam.append((left << (30 + right_bits)) | (core << right_bits) | right)
+    fam = np.array(fam, np.uint64)
+    kk = np.concatenate([keys[:11000], fam])
+    tt = np.concatenate([targets[:11000], (np.arange(3000) % 5000 + 2).astype(np.uint32)])
+    assert kk.size > 0.85 * (1 << 14)
+    odb = oracle_db(parent, kk, tt, 14)
+    q = np.concatenate([kk, fam ^ np.uint64(1), keys[11000:14000]])
+    exp = odb.get(q)
+    for flags in (0, KID_FLAG_REF_GEOMETRY):
+        db = KmerDB(kk, tt, parent, k=K, log2_slots=14, flags=flags)
+        assert np.array_equal(db.lookup(q), exp)
+        # reads made of the family k-mers back to back
+        reads = []
+        for i in range(400):
+            s = b"".join(synth.key_to_seq(int(fam[(i * 7 + j) % 3000])).encode() for j in range(5))
+            reads.append(s)
+        data, off = concat_reads(reads)
+        os_ = ob.OracleSample(odb)
+        e = os_.classify(data, off)
+        smp = db.sample()
+        assert np.array_equal(smp.classify(data, off), e)
+        g, u = smp.end(); eg, eu = os_.counts()
+        assert np.array_equal(g, eg) and np.array_equal(u, eu)
+        smp.close(); db.close()
 
 
 def test_table_full_and_bad_inputs():

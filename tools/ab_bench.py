@@ -18,7 +18,8 @@ for lib in args:
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode().strip().splitlines()
     try:
         d = json.loads(out[-1]); r = d["roofline"]
-        print("%-40s %7.1f Mpairs/s  kernel %.3f ms  %.2f Glookups/s  %.1f GB/s alg" % (
-            os.path.basename(lib), d["value"] / 1e6, r["avg_kernel_ms"], r["lookups_per_s"] / 1e9, r["achieved"]), flush=True)
+        print("%-40s %7.1f Mpairs/s  kernel %.3f ms  %.2f Glookups/s  %.1f GB/s alg  cells/lookup %.3f" % (
+            os.path.basename(lib), d["value"] / 1e6, r["avg_kernel_ms"], r["lookups_per_s"] / 1e9, r["achieved"],
+            r["cells_read_per_launch"] / r["lookups_per_launch"]), flush=True)
     except Exception as e:
         print(lib, "FAILED", e, out[-3:])
