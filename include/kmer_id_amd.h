@@ -120,11 +120,12 @@ int kid_classify_batch(kid_sample *s, const uint8_t *bases, const uint64_t *offs
                        const int32_t *start, const int32_t *stop, uint64_t n_reads,
                        uint32_t *out_final_targ);
 /* Device-resident form, asynchronous on `stream` (a hipStream_t, NULL = default
- * stream).  The allocation behind d_bases must extend at least 16 bytes past
- * offsets[n_reads] (the kernel reads aligned 16-byte chunks).                     */
-int kid_classify_batch_device(kid_sample *s, const void *d_bases, const void *d_offsets,
-                              const void *d_start, const void *d_stop, uint64_t n_reads,
-                              void *d_out_final_targ, void *stream);
+ * stream).  bases_nbytes = offsets[n_reads] (size of the read text); d_bases must be
+ * 16-byte aligned and its allocation must extend at least 16 bytes past bases_nbytes
+ * (the pack kernel reads aligned 16-byte chunks).                                 */
+int kid_classify_batch_device(kid_sample *s, const void *d_bases, uint64_t bases_nbytes,
+                              const void *d_offsets, const void *d_start, const void *d_stop,
+                              uint64_t n_reads, void *d_out_final_targ, void *stream);
 /* Fixed-length reads laid out back to back (read r = bases[r*read_len, (r+1)*read_len)),
  * whole reads, no offsets array: the layout of the synthetic roofline runs.      */
 int kid_classify_fixed_device(kid_sample *s, const void *d_bases, uint32_t read_len,

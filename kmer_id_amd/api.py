@@ -131,9 +131,9 @@ class Sample:
         check(self._lib.kid_classify_batch(self._h, _ptr(bases), _ptr(offsets), _ptr(start), _ptr(stop), n, _ptr(out)))
         return out
 
-    def classify_device(self, d_bases, d_offsets, n_reads, d_start=0, d_stop=0, d_out=0, stream=0):
+    def classify_device(self, d_bases, bases_nbytes, d_offsets, n_reads, d_start=0, d_stop=0, d_out=0, stream=0):
         """Asynchronous, device-resident inputs (raw pointers)."""
-        check(self._lib.kid_classify_batch_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offsets),
+        check(self._lib.kid_classify_batch_device(self._h, C.c_void_p(d_bases), bases_nbytes, C.c_void_p(d_offsets),
                                                   C.c_void_p(d_start or None), C.c_void_p(d_stop or None), n_reads,
                                                   C.c_void_p(d_out or None), C.c_void_p(stream or None)))
 

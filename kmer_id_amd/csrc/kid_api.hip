@@ -53,6 +53,12 @@ struct kid_sample {
     uint32_t *seen = nullptr;
     uint64_t seen_words = 0;
     hipStream_t stream = nullptr;
+    // per-batch scratch of the device pipeline (prepare -> pack -> classify), grown on demand
+    KidReadDesc *sc_desc = nullptr;
+    uint64_t sc_desc_cap = 0;
+    uint32_t *sc_codes = nullptr;
+    uint16_t *sc_inval = nullptr;
+    uint64_t sc_chunks_cap = 0;
     // staging for the host-buffer entry point
     uint8_t *st_bases = nullptr;
     uint64_t st_bases_cap = 0;
@@ -415,6 +421,9 @@ extern "C" void kid_sample_destroy(kid_sample *s)
     if (s->ucount) hipFree(s->ucount);
     if (s->stats) hipFree(s->stats);
     if (s->seen) hipFree(s->seen);
+    if (s->sc_desc) hipFree(s->sc_desc);
+    if (s->sc_codes) hipFree(s->sc_codes);
+    if (s->sc_inval) hipFree(s->sc_inval);
     if (s->st_bases) hipFree(s->st_bases);
     if (s->st_offsets) hipFree(s->st_offsets);
     if (s->st_start) hipFree(s->st_start);
@@ -469,12 +478,35 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
     return KID_OK;
 }
 
-// launch geometry: 512-thread workgroups (8 waves), persistent over the reads.
-// The gcount histogram lives in LDS when 4 workgroups per CU still fit.
-static int kid_launch_classify(kid_sample *s, const KidBatch &b, hipStream_t stream)
+// One batch = three launches on `stream`: kid_prepare_kernel (read descriptors + range checks),
+// kid_pack_kernel (ASCII -> 2 bit + invalid mask over the whole buffer, every lane busy) and
+// kid_classify_kernel (512-thread workgroups = 8 waves, persistent over the reads; the gcount
+// histogram lives in LDS when 4 workgroups per CU still fit).
+static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_nbytes, hipStream_t stream)
 {
     kid_db *db = s->db;
     if (b.n == 0) return KID_OK;
+    const uint64_t nchunks = (bases_nbytes + 15) / 16;
+    if (b.n > s->sc_desc_cap) {
+        if (s->sc_desc) hipFree(s->sc_desc);
+        s->sc_desc = nullptr; s->sc_desc_cap = 0;
+        KID_HIP(hipMalloc(&s->sc_desc, b.n * sizeof(KidReadDesc)));
+        s->sc_desc_cap = b.n;
+    }
+    if (nchunks > s->sc_chunks_cap) {
+        if (s->sc_codes) hipFree(s->sc_codes);
+        if (s->sc_inval) hipFree(s->sc_inval);
+        s->sc_codes = nullptr; s->sc_inval = nullptr; s->sc_chunks_cap = 0;
+        KID_HIP(hipMalloc(&s->sc_codes, (nchunks + 64) * 4));
+        KID_HIP(hipMalloc(&s->sc_inval, (nchunks + 64) * 2));
+        s->sc_chunks_cap = nchunks;
+    }
+    hipLaunchKernelGGL(kid_prepare_kernel, dim3(kid_grid_for(b.n, 256, db->num_cu * 8)), dim3(256), 0, stream, b, db->info.k,
+                       s->sc_desc, s->stats);
+    if (nchunks)
+        hipLaunchKernelGGL(kid_pack_kernel, dim3(kid_grid_for(nchunks, 256, db->num_cu * 16)), dim3(256), 0, stream, b.bases,
+                           nchunks, db->d.u_is_t, s->sc_codes, s->sc_inval);
+    KidPacked pk{s->sc_codes, s->sc_inval, s->sc_desc, b.out_final, b.n};
     const int block = 512, wpb = block / 64;
     const uint32_t ntar = (uint32_t)db->info.ntar;
     const bool hist = (ntar * 4u <= 36u * 1024u);
@@ -483,7 +515,7 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, hipStream_t str
     const int grid = kid_grid_for(b.n, wpb, db->num_cu * 4);
     KidSampleDev sd{s->gcount, s->seen, s->stats};
     const bool rows = db->rows != nullptr;
-#define KID_LAUNCH(R, H, M) hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M>), dim3(grid), dim3(block), lds, stream, db->d, b, sd, hist_words)
+#define KID_LAUNCH(R, H, M) hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M>), dim3(grid), dim3(block), lds, stream, db->d, pk, sd, hist_words)
     const bool ml = db->d.minloc != 0;
     if (rows && hist && ml) KID_LAUNCH(true, true, true);
     else if (rows && hist) KID_LAUNCH(true, true, false);
@@ -498,8 +530,9 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, hipStream_t str
     return KID_OK;
 }
 
-extern "C" int kid_classify_batch_device(kid_sample *s, const void *d_bases, const void *d_offsets, const void *d_start,
-                                         const void *d_stop, uint64_t n_reads, void *d_out_final_targ, void *stream)
+extern "C" int kid_classify_batch_device(kid_sample *s, const void *d_bases, uint64_t bases_nbytes, const void *d_offsets,
+                                         const void *d_start, const void *d_stop, uint64_t n_reads, void *d_out_final_targ,
+                                         void *stream)
 {
     if (!s || (n_reads && (!d_bases || !d_offsets))) return kid_fail(KID_ERR_ARG, "null argument");
     if (((uintptr_t)d_bases & 15u) != 0) return kid_fail(KID_ERR_ARG, "d_bases must be 16-byte aligned");
@@ -514,7 +547,7 @@ extern "C" int kid_classify_batch_device(kid_sample *s, const void *d_bases, con
     b.out_final = (uint32_t *)d_out_final_targ;
     b.n = n_reads;
     b.fixed_len = 0;
-    return kid_launch_classify(s, b, (hipStream_t)stream);
+    return kid_launch_classify(s, b, bases_nbytes, (hipStream_t)stream);
 }
 
 extern "C" int kid_classify_fixed_device(kid_sample *s, const void *d_bases, uint32_t read_len, uint64_t n_reads,
@@ -530,7 +563,7 @@ extern "C" int kid_classify_fixed_device(kid_sample *s, const void *d_bases, uin
     b.out_final = (uint32_t *)d_out_final_targ;
     b.n = n_reads;
     b.fixed_len = read_len;
-    return kid_launch_classify(s, b, (hipStream_t)stream);
+    return kid_launch_classify(s, b, n_reads * (uint64_t)read_len, (hipStream_t)stream);
 }
 
 extern "C" int kid_classify_batch(kid_sample *s, const uint8_t *bases, const uint64_t *offsets, const int32_t *start,
@@ -592,7 +625,7 @@ extern "C" int kid_classify_batch(kid_sample *s, const uint8_t *bases, const uin
     b.stop = start ? s->st_stop : nullptr;
     b.out_final = s->st_out;
     b.n = n_reads;
-    rc = kid_launch_classify(s, b, st);
+    rc = kid_launch_classify(s, b, nbytes, st);
     if (rc != KID_OK) return rc;
     if (out_final_targ) KID_HIP(hipMemcpyAsync(out_final_targ, s->st_out, n_reads * 4, hipMemcpyDeviceToHost, st));
     KID_HIP(hipStreamSynchronize(st));

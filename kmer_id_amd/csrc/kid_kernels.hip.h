@@ -55,7 +55,7 @@ struct KidDevDb {
     int32_t ntar;
 };
 
-struct KidBatch {
+struct KidBatch { // what the caller handed over
     const uint8_t *bases;
     const uint64_t *offsets; // null: fixed_len layout
     const int32_t *start;    // nullable
@@ -63,6 +63,22 @@ struct KidBatch {
     uint32_t *out_final;     // nullable
     uint64_t n;
     uint32_t fixed_len;
+};
+
+// per-read descriptor written by kid_prepare_kernel: absolute index of the first base of the
+// classified range and the number of k-mer windows in it (<= 0: none)
+struct KidReadDesc {
+    uint64_t first_base;
+    int32_t n_kmers;
+    uint32_t pad;
+};
+
+struct KidPacked { // what the classify kernel reads
+    const uint32_t *codes;  // one word per 16 bases of the whole batch buffer, first base in the top bits
+    const uint16_t *inval;  // one bit per base: not ACGTacgt (Uu)
+    const KidReadDesc *desc;
+    uint32_t *out_final;    // nullable
+    uint64_t n;
 };
 
 struct KidSampleDev {
@@ -188,10 +204,50 @@ __device__ __forceinline__ void kid_pack16(const uint4 v, const uint32_t u_is_t,
     }
 }
 
+// ------------------------------------------------------------------ batch preparation
+// [start, stop] -> descriptor; the range checks the reference leaves to string::at() happen here
+__global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, unsigned long long *stats)
+{
+    uint32_t bad = 0;
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < b.n; r += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t off;
+        int64_t rl;
+        if (b.offsets) { off = b.offsets[r]; rl = (int64_t)(b.offsets[r + 1] - off); }
+        else { off = r * (uint64_t)b.fixed_len; rl = b.fixed_len; }
+        int64_t s0 = b.start ? (int64_t)b.start[r] : 0;
+        int64_t e0 = b.stop ? (int64_t)b.stop[r] : rl - 1;
+        if (s0 <= e0 && (s0 < 0 || e0 >= rl)) { // never read outside the read; reported as KID_ERR_ARG
+            bad++;
+            if (s0 < 0) s0 = 0;
+            if (e0 >= rl) e0 = rl - 1;
+        }
+        KidReadDesc d;
+        int64_t nk = e0 - s0 + 1 - (k - 1);
+        if (s0 > e0) nk = 0;
+        d.first_base = off + (uint64_t)(s0 > 0 ? s0 : 0);
+        d.n_kmers = (int32_t)(nk > 0x7FFFFFFF ? 0x7FFFFFFF : nk);
+        d.pad = 0;
+        desc[r] = d;
+    }
+    if (bad) atomicAdd(&stats[4], (unsigned long long)bad);
+}
+
+// ASCII -> 2 bits per base + invalid mask for the whole batch buffer, 16 bases per lane
+__global__ void kid_pack_kernel(const uint8_t *bases, uint64_t nchunks, uint32_t u_is_t, uint32_t *codes, uint16_t *inval)
+{
+    for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < nchunks; c += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(bases + 16ull * c);
+        uint32_t w, m;
+        kid_pack16(v, u_is_t, w, m);
+        codes[c] = w;
+        inval[c] = (uint16_t)m;
+    }
+}
+
 // ------------------------------------------------------------------ classify
 // One wavefront per read.  Per segment of <= 960 k-mers:
-//   1. every lane loads one aligned 16-byte chunk of the read (coalesced) and
-//      packs it to 2 bits/base into the wave's private LDS strip;
+//   1. every lane copies one packed word (16 bases, 2 bits each) and its invalid mask from the
+//      batch's packed image (kid_pack_kernel) into the wave's private LDS strip;
 //   2. lane i extracts the k-mer window starting at base i from LDS with two
 //      shifts (no serial rolling), derives the reverse complement with a bit
 //      reversal and takes min(); with the minimizer-localised geometry the wave
@@ -203,7 +259,7 @@ __device__ __forceinline__ void kid_pack16(const uint4 v, const uint32_t u_is_t,
 //   5. hit cells are marked in the sample's seen-bitmap (ucount, :596-603).
 // gcount is accumulated in an LDS histogram per workgroup and flushed once.
 template <int U, bool ROWS, bool HIST, bool MINLOC>
-__global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db, const KidBatch b, const KidSampleDev s,
+__global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db, const KidPacked b, const KidSampleDev s,
                                                             const uint32_t hist_words)
 {
     extern __shared__ uint32_t kid_smem[];
@@ -224,48 +280,33 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
     const int mlen = k - (KID_MIN_W - 1);
     const uint64_t gw = (uint64_t)blockIdx.x * wpb + wib;
     const uint64_t nw = (uint64_t)gridDim.x * wpb;
-    uint64_t n_lookups = 0, n_probes = 0; // per lane
-    uint32_t n_hits = 0, n_reads = 0, n_err = 0; // lane 0 / uniform
-    uint32_t pend_t = 0, pend_n = 0;             // !HIST: run-length buffer in front of the global gcount atomics
+    uint32_t n_lookups = 0, n_probes = 0;  // per lane, per workgroup-lifetime: far below 2^32
+    uint32_t n_hits = 0, n_reads = 0;      // wave-uniform
+    uint32_t pend_t = 0, pend_n = 0;       // !HIST: run-length buffer in front of the global gcount atomics
 
     for (uint64_t r = gw; r < b.n; r += nw) {
-        uint64_t off;
-        int64_t rl;
-        if (b.offsets) {
-            off = b.offsets[r];
-            rl = (int64_t)(b.offsets[r + 1] - off);
-        } else {
-            off = r * (uint64_t)b.fixed_len;
-            rl = b.fixed_len;
-        }
-        int64_t s0 = b.start ? (int64_t)b.start[r] : 0;
-        int64_t e0 = b.stop ? (int64_t)b.stop[r] : rl - 1;
-        if (s0 < 0 || e0 >= rl) { // the reference would throw from string::at(); never read out of bounds here
-            n_err++;
-            if (s0 < 0) s0 = 0;
-            if (e0 >= rl) e0 = rl - 1;
-        }
-        off = __builtin_amdgcn_readfirstlane((uint32_t)off) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(off >> 32)) << 32);
-        const int32_t s0u = __builtin_amdgcn_readfirstlane((int32_t)s0);
-        const int64_t nk = (int64_t)__builtin_amdgcn_readfirstlane((int32_t)(e0 - s0 + 1 - (k - 1)));
+        const KidReadDesc d = b.desc[r];
+        const uint64_t first = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(d.first_base >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)d.first_base);
+        const int64_t nk = (int64_t)__builtin_amdgcn_readfirstlane(d.n_kmers);
 
         uint32_t final_t = 0;
         uint4 frow = make_uint4(0, 0, 0, 0);
 
         for (int64_t seg = 0; seg < nk; seg += KID_SEG_KMERS) {
             const uint32_t segk = (uint32_t)((nk - seg) < KID_SEG_KMERS ? (nk - seg) : KID_SEG_KMERS);
-            const uint64_t b0 = off + (uint64_t)s0u + (uint64_t)seg; // first base of the segment
+            const uint64_t b0 = first + (uint64_t)seg; // first base of the segment
             const uint32_t nb = segk + (uint32_t)k - 1;
-            const uint64_t a0 = b0 & ~15ull;
+            const uint64_t c0 = b0 >> 4;
             const uint32_t sh = (uint32_t)(b0 & 15ull);
             const uint32_t nchunks = (sh + nb + 15u) >> 4; // <= 64
 
-            // ---- 1. pack
+            // ---- 1. stage the packed segment
             {
                 uint32_t codes = 0, inv = 0;
                 if (lane < nchunks) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(b.bases + a0 + 16ull * lane);
-                    kid_pack16(v, db.u_is_t, codes, inv);
+                    codes = b.codes[c0 + lane];
+                    inv = b.inval[c0 + lane];
                 }
                 W[lane] = codes;
                 IM16[lane] = (uint16_t)inv;
@@ -416,17 +457,17 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
             if (v) atomicAdd(&s.gcount[i], (unsigned long long)v);
         }
     }
+    unsigned long long tl = n_lookups, tp = n_probes;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        n_lookups += __shfl_xor(n_lookups, o);
-        n_probes += __shfl_xor(n_probes, o);
+        tl += __shfl_xor(tl, o);
+        tp += __shfl_xor(tp, o);
     }
     if (lane == 0) {
         if (n_reads) atomicAdd(&s.stats[0], (unsigned long long)n_reads);
-        if (n_lookups) atomicAdd(&s.stats[1], (unsigned long long)n_lookups);
-        if (n_probes) atomicAdd(&s.stats[2], (unsigned long long)n_probes);
+        if (tl) atomicAdd(&s.stats[1], tl);
+        if (tp) atomicAdd(&s.stats[2], tp);
         if (n_hits) atomicAdd(&s.stats[3], (unsigned long long)n_hits);
-        if (n_err) atomicAdd(&s.stats[4], (unsigned long long)n_err);
     }
 }
 
