@@ -284,11 +284,46 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
     uint32_t n_hits = 0, n_reads = 0;      // wave-uniform
     uint32_t pend_t = 0, pend_n = 0;       // !HIST: run-length buffer in front of the global gcount atomics
 
+    // Software pipeline over the reads of this wave: the descriptor is fetched two reads ahead and
+    // the first packed segment one read ahead, so that neither sits on the critical path of a read
+    // (a wave is latency-bound: every read is a chain of dependent memory round trips).
+    KidReadDesc d_cur, d_nxt;
+    d_cur.first_base = 0; d_cur.n_kmers = 0; d_cur.pad = 0;
+    d_nxt = d_cur;
+    if (gw < b.n) d_cur = b.desc[gw];
+    if (gw + nw < b.n) d_nxt = b.desc[gw + nw];
+    uint32_t pf_codes = 0, pf_inv = 0;
+    {
+        const int32_t nk0 = d_cur.n_kmers;
+        const uint32_t sg = nk0 < KID_SEG_KMERS ? (uint32_t)(nk0 > 0 ? nk0 : 0) : KID_SEG_KMERS;
+        const uint32_t nch = nk0 > 0 ? (((uint32_t)d_cur.first_base & 15u) + sg + (uint32_t)k - 1u + 15u) >> 4 : 0u;
+        if (lane < nch) {
+            pf_codes = b.codes[(d_cur.first_base >> 4) + lane];
+            pf_inv = b.inval[(d_cur.first_base >> 4) + lane];
+        }
+    }
+
     for (uint64_t r = gw; r < b.n; r += nw) {
-        const KidReadDesc d = b.desc[r];
-        const uint64_t first = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(d.first_base >> 32)) << 32) |
-                               (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)d.first_base);
-        const int64_t nk = (int64_t)__builtin_amdgcn_readfirstlane(d.n_kmers);
+        const uint64_t first = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(d_cur.first_base >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)d_cur.first_base);
+        const int64_t nk = (int64_t)__builtin_amdgcn_readfirstlane(d_cur.n_kmers);
+        const uint32_t st_codes = pf_codes, st_inv = pf_inv; // first segment of this read, already here
+        // issue the loads for the reads behind this one
+        KidReadDesc d_nn;
+        d_nn.first_base = 0; d_nn.n_kmers = 0; d_nn.pad = 0;
+        if (r + 2 * nw < b.n) d_nn = b.desc[r + 2 * nw];
+        pf_codes = 0; pf_inv = 0;
+        {
+            const int32_t nk1 = d_nxt.n_kmers;
+            const uint32_t sg = nk1 < KID_SEG_KMERS ? (uint32_t)(nk1 > 0 ? nk1 : 0) : KID_SEG_KMERS;
+            const uint32_t nch = nk1 > 0 ? (((uint32_t)d_nxt.first_base & 15u) + sg + (uint32_t)k - 1u + 15u) >> 4 : 0u;
+            if (lane < nch) {
+                pf_codes = b.codes[(d_nxt.first_base >> 4) + lane];
+                pf_inv = b.inval[(d_nxt.first_base >> 4) + lane];
+            }
+        }
+        d_cur = d_nxt;
+        d_nxt = d_nn;
 
         uint32_t final_t = 0;
         uint4 frow = make_uint4(0, 0, 0, 0);
@@ -303,10 +338,13 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
 
             // ---- 1. stage the packed segment
             {
-                uint32_t codes = 0, inv = 0;
-                if (lane < nchunks) {
-                    codes = b.codes[c0 + lane];
-                    inv = b.inval[c0 + lane];
+                uint32_t codes = st_codes, inv = st_inv;
+                if (seg != 0) { // long reads: later segments are fetched on the spot
+                    codes = 0; inv = 0;
+                    if (lane < nchunks) {
+                        codes = b.codes[c0 + lane];
+                        inv = b.inval[c0 + lane];
+                    }
                 }
                 W[lane] = codes;
                 IM16[lane] = (uint16_t)inv;
