@@ -257,7 +257,10 @@ static int kid_db_build_common(const uint64_t *h_keys, const uint32_t *h_targets
     const bool host_build = (max_probes > 0) || (flags & KID_FLAG_HOST_BUILD);
     // minimizer-localised placement needs an unbounded probe loop (results must not depend on the
     // cell geometry) and a window of 16 m-mers with 8 <= m <= 16
-    const uint32_t minloc = (!host_build && !(flags & KID_FLAG_REF_GEOMETRY) && k >= 23) ? 1u : 0u;
+    // (7 of 8 cells hold entries, and chains need free lines: at most 80 % of the cells may be taken)
+    const uint32_t minloc = (!host_build && !(flags & KID_FLAG_REF_GEOMETRY) && k >= 23 && n <= (nslots / 10) * 8) ? 1u : 0u;
+    const uint32_t line_bits = (uint32_t)log2_slots - 3u;
+    const uint32_t line_shift = 32u - line_bits, line_mask = (uint32_t)((nslots >> 3) - 1);
     if (host_build) {
         std::vector<uint64_t> hk;
         std::vector<uint32_t> ht;
@@ -296,9 +299,9 @@ static int kid_db_build_common(const uint64_t *h_keys, const uint32_t *h_targets
             KID_DB_HIP(hipMemset(d_occ, 0, 16));
             const int grid = kid_grid_for(n, 256, db->num_cu * 16);
             hipLaunchKernelGGL(kid_build_insert_kernel, dim3(grid), dim3(256), 0, 0, db->table, (uint32_t)(nslots - 1), dkc,
-                               dtc, n, (uint32_t)ntar, d_occ, k, minloc);
+                               dtc, n, (uint32_t)ntar, d_occ, k, minloc, line_shift, line_mask);
             hipLaunchKernelGGL(kid_build_firstwins_kernel, dim3(grid), dim3(256), 0, 0, db->table, (uint32_t)(nslots - 1),
-                               dkc, dtc, n, k, minloc);
+                               dkc, dtc, n, k, minloc, line_shift, line_mask);
             hipError_t e = hipDeviceSynchronize();
             unsigned long long occ[2] = {0, 0};
             if (e == hipSuccess) e = hipMemcpy(occ, d_occ, 16, hipMemcpyDeviceToHost);
@@ -319,6 +322,8 @@ static int kid_db_build_common(const uint64_t *h_keys, const uint32_t *h_targets
     db->d.k = k;
     db->d.u_is_t = (flags & KID_FLAG_U_IS_T) ? 1u : 0u;
     db->d.minloc = minloc;
+    db->d.line_shift = line_shift;
+    db->d.line_mask = line_mask;
     db->info.geometry = (int32_t)minloc;
     db->d.rows = db->rows;
     db->d.parent = db->parent;

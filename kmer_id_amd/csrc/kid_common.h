@@ -68,20 +68,20 @@ KID_HD int kid_base_code(uint8_t c, bool u_is_t)
 }
 
 // ---------------------------------------------------------------- minimizer-localised table geometry
-// The GPU-native table keeps the reference's cells and its first-insert-wins lookup results but
-// places a key by the MINIMIZER of its k-mer: all k-mers that share their smallest (hashed,
-// strand-symmetric) m-mer, m = k - 15, live in one 128-byte line of 8 cells.  Consecutive
+// The GPU-native table keeps the reference's 16-byte cells and its first-insert-wins lookup
+// results but places a key by the MINIMIZER of its k-mer: all k-mers that share their smallest
+// (hashed, strand-symmetric) m-mer, m = k - 15, go to one 128-byte line = 8 cells.  Consecutive
 // k-mers of a read share their minimizer for ~8.5 positions, so the lanes of a wavefront
-// (consecutive read positions) hit ~8 distinct lines per 64 lookups instead of 64 -- the
-// lookups coalesce.  Only legal where the probe loop is unbounded (newkmer_10nx, kmer_read_vf6):
-// there the answer depends on the key -> first target map alone, not on where cells sit.
-#define KID_MIN_W 16      // m-mers per k-mer window
-#ifndef KID_LINE_LOG2
-#define KID_LINE_LOG2 3   // cells per line = 8 (128 bytes)
-#endif
-#ifndef KID_CHEAP_HASH
-#define KID_CHEAP_HASH 1 // one multiply per hash: measured 6 % faster, same table quality
-#endif
+// (consecutive read positions) touch ~8 distinct lines per 64 lookups instead of 64 -- the
+// lookups coalesce.  Inside a line, cell 0 is a header {7 x 16-bit key fingerprints, count}:
+// one 16-byte load answers "absent" (99 % of all lookups) no matter how crowded the line is;
+// a fingerprint match costs one more load.  A full line (7 entries) chains into the next one.
+// Only legal where the probe loop is unbounded (newkmer_10nx, kmer_read_vf6): there the answer
+// depends on the key -> first target map alone, not on where cells sit.
+#define KID_MIN_W 16        // m-mers per k-mer window
+#define KID_LINE_CELLS 8    // header + 7 entries
+#define KID_LINE_ENTRIES 7
+#define KID_HDR_FULL 8u     // header count value: 7 entries stored and the chain continues in the next line
 
 KID_HD uint32_t kid_rev2_32(uint32_t x)
 {
@@ -98,17 +98,13 @@ KID_HD uint32_t kid_rev2_32(uint32_t x)
 }
 
 // hash of the canonical form of the m-mer f (2m bits, m <= 16); identical for an m-mer and its
-// reverse complement
+// reverse complement.  One multiply + xorshift: enough to break up lexicographic order.
 KID_HD uint32_t kid_mmer_hash(uint32_t f, int m)
 {
     const uint32_t r = (~kid_rev2_32(f)) >> (32 - 2 * m);
     uint32_t h = f < r ? f : r;
     h *= 0x9E3779B1u;
     h ^= h >> 15;
-#if !KID_CHEAP_HASH
-    h *= 0x85EBCA77u;
-    h ^= h >> 13;
-#endif
     return h;
 }
 
@@ -125,22 +121,17 @@ KID_HD uint32_t kid_minimizer_of_key(uint64_t keyF, int k)
     return g;
 }
 
-// first cell of the probe sequence: line chosen by the minimizer, cell in the line by the key
-KID_HD uint32_t kid_minloc_home(uint32_t g, uint64_t key, uint32_t slot_mask)
+// line of a minimizer: top bits of one more product (line_shift = 32 - log2(number of lines))
+KID_HD uint32_t kid_minloc_line(uint32_t g, uint32_t line_shift)
 {
-#if KID_CHEAP_HASH
-    // multiplicative hashing: the line comes from the top bits of one product
-    const uint32_t l = (g * 0xC2B2AE3Du) >> KID_LINE_LOG2;
-    const uint32_t sub = ((uint32_t)key * 0x9E3779B1u) >> (32 - KID_LINE_LOG2);
-    return ((l << KID_LINE_LOG2) | sub) & slot_mask; // slot_mask keeps the low log2_slots bits
-#else
-    uint32_t l = g * 0xC2B2AE3Du;
-    l ^= l >> 16;
-    l *= 0x27D4EB2Fu;
-    l ^= l >> 15;
-    const uint32_t sub = ((uint32_t)key * 0x9E3779B1u) >> (32 - KID_LINE_LOG2);
-    return ((l << KID_LINE_LOG2) | sub) & slot_mask;
-#endif
+    return (g * 0xC2B2AE3Du) >> line_shift;
+}
+
+// 16-bit fingerprint of a key kept in the line header; never 0 (0 = unused header slot)
+KID_HD uint32_t kid_key_fp(uint64_t key)
+{
+    const uint32_t f = ((uint32_t)key * 0x9E3779B1u + (uint32_t)(key >> 32) * 0x85EBCA77u) >> 16;
+    return f ? f : 1u;
 }
 
 // ---------------------------------------------------------------- synthetic data

@@ -49,6 +49,8 @@ struct KidDevDb {
     int k;
     uint32_t u_is_t;
     uint32_t minloc; // 1: minimizer-localised geometry (kid_common.h), 0: the reference's fmix64 + triangular probing
+    uint32_t line_shift; // minloc: 32 - log2(lines)
+    uint32_t line_mask;  // minloc: lines - 1
     const uint4 *rows; // null when the tree does not fit the row encoding
     const int32_t *parent;
     const int32_t *depth;
@@ -89,22 +91,51 @@ struct KidSampleDev {
 
 // ------------------------------------------------------------------ hash lookup
 // Hashtable::getHash, newkmer_10nx.cpp:204-233 (+ probe cap kmer_read_m3.cpp:232)
+// exact per-halfword equality of the 7 header fingerprints with fp: bit j set = slot j matches
+__device__ __forceinline__ uint32_t kid_hdr_match(const uint4 &h, uint32_t fp)
+{
+    const uint32_t rep = fp * 0x00010001u;
+    const uint32_t w[4] = {h.x ^ rep, h.y ^ rep, h.z ^ rep, (h.w ^ rep) | 0xFFFF0000u}; // upper half of .w is the count
+    uint32_t m = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        // bit 15 / bit 31 set exactly where a halfword of w[d] is zero
+        const uint32_t z = ~(((w[d] & 0x7FFF7FFFu) + 0x7FFF7FFFu) | w[d] | 0x7FFF7FFFu);
+        m |= (((z >> 15) & 1u) | ((z >> 30) & 2u)) << (2 * d);
+    }
+    return m & 0x7Fu;
+}
+
+// Lookup in the minimizer-localised table: header, then the cells whose fingerprint matches, then
+// the next line while the chain continues.  Returns the target (0 = absent); ncell = cells read.
+__device__ __forceinline__ uint32_t kid_bucket_lookup(const KidDevDb &db, uint64_t key, uint32_t g, uint32_t &slot, uint32_t &ncell)
+{
+    uint32_t line = kid_minloc_line(g, db.line_shift);
+    const uint32_t fp = kid_key_fp(key);
+    ncell = 0;
+    slot = 0;
+    for (;;) {
+        const uint32_t base = line * KID_LINE_CELLS;
+        const uint4 h = db.table[base];
+        ncell++;
+        uint32_t m = kid_hdr_match(h, fp);
+        while (m) {
+            const uint32_t j = (uint32_t)__builtin_ctz(m);
+            m &= m - 1;
+            const uint4 c = db.table[base + 1u + j];
+            ncell++;
+            if (c.x == (uint32_t)key && c.y == (uint32_t)(key >> 32)) { slot = base + 1u + j; return c.z; }
+        }
+        if ((h.w >> 16) < KID_HDR_FULL) return 0;
+        line = (line + 1u) & db.line_mask;
+    }
+}
+
 __device__ __forceinline__ uint32_t kid_dev_lookup(const KidDevDb &db, uint64_t key, uint32_t &slot, uint32_t &nprobe)
 {
     uint32_t i = 0, res = 0;
     slot = 0;
-    if (db.minloc) {
-        const uint32_t home = kid_minloc_home(kid_minimizer_of_key(key, db.k), key, db.slot_mask);
-        for (;;) { // linear probing; the table always keeps >= 32 empty cells
-            const uint32_t idx = (home + i) & db.slot_mask;
-            ++i;
-            const uint4 c = db.table[idx];
-            if (c.z == 0) break;
-            if (c.x == (uint32_t)key && c.y == (uint32_t)(key >> 32)) { res = c.z; slot = idx; break; }
-        }
-        nprobe = i;
-        return res;
-    }
+    if (db.minloc) return kid_bucket_lookup(db, key, kid_minimizer_of_key(key, db.k), slot, nprobe);
     const uint64_t hash = kid_fmix64(key);
     uint64_t reprobe = 0;
     do {
@@ -357,7 +388,7 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
             // ---- 2..5 per group of U*64 windows
             for (uint32_t t0 = 0; t0 < segk; t0 += U * 64u) {
                 uint64_t key[U];
-                uint32_t hlo[U]; // first cell of the probe sequence
+                uint32_t hlo[U]; // reference geometry: first cell of the probe sequence; minloc: the minimizer
                 bool act[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -398,38 +429,83 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
                         const uint32_t same = nxt;
                         nxt = (uint32_t)__shfl((int)P[u + 1], (int)src);
                         const uint32_t pn = (lane + 15u < 64u) ? same : nxt;
-                        const uint32_t g = S[u] < pn ? S[u] : pn;
-                        hlo[u] = kid_minloc_home(g, key[u], db.slot_mask);
+                        hlo[u] = S[u] < pn ? S[u] : pn;
                     }
                 }
                 uint32_t tgt[U], slot[U], step[U];
-                uint64_t rp[U];
 #pragma unroll
-                for (int u = 0; u < U; u++) { tgt[u] = 0; slot[u] = 0; step[u] = 0; rp[u] = 0; }
-                bool any = false;
-#pragma unroll
-                for (int u = 0; u < U; u++) any |= act[u];
-                while (any) {
-                    uint4 c[U];
-                    uint32_t idx[U];
+                for (int u = 0; u < U; u++) { tgt[u] = 0; slot[u] = 0; step[u] = 0; }
+                if (MINLOC) {
+                    // one 16-byte header per lookup settles every absent key; lanes that share a
+                    // minimizer read the same header (one sector for all of them)
+                    uint4 hd[U];
+                    uint32_t mm[U], fp[U], line[U];
 #pragma unroll
                     for (int u = 0; u < U; u++) {
-                        idx[u] = (hlo[u] + (uint32_t)rp[u]) & db.slot_mask;
-                        c[u] = make_uint4(0, 0, 0, 0);
-                        if (act[u]) c[u] = kid_load_cell(db.table, idx[u]);
+                        line[u] = kid_minloc_line(hlo[u], db.line_shift);
+                        hd[u] = make_uint4(0, 0, 0, 0);
+                        if (act[u]) hd[u] = kid_load_cell(db.table, line[u] * KID_LINE_CELLS);
                     }
-                    any = false;
+                    bool more = false;
 #pragma unroll
                     for (int u = 0; u < U; u++) {
-                        if (act[u]) {
-                            step[u]++;
-                            rp[u] += MINLOC ? 1u : step[u]; // linear inside/after the line vs the reference's triangular steps
-                            if (c[u].z == 0) act[u] = false;
-                            else if (c[u].x == (uint32_t)key[u] && c[u].y == (uint32_t)(key[u] >> 32)) {
-                                tgt[u] = c[u].z; slot[u] = idx[u]; act[u] = false;
-                            } else if (!MINLOC && (!(rp[u] < db.nslots) || (db.max_probes != 0 && step[u] >= db.max_probes))) act[u] = false;
+                        fp[u] = kid_key_fp(key[u]);
+                        mm[u] = act[u] ? kid_hdr_match(hd[u], fp[u]) : 0u;
+                        step[u] = act[u] ? 1u : 0u;
+                        more |= act[u] && (mm[u] != 0 || (hd[u].w >> 16) >= KID_HDR_FULL);
+                    }
+                    if (more) { // ~1 % of the lanes: fingerprint matches (hits) and chained lines
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            bool go = act[u] && (mm[u] != 0 || (hd[u].w >> 16) >= KID_HDR_FULL);
+                            uint4 h = hd[u];
+                            uint32_t m = mm[u], ln = line[u];
+                            while (go) {
+                                if (m) {
+                                    const uint32_t j = (uint32_t)__builtin_ctz(m);
+                                    m &= m - 1;
+                                    const uint32_t idx = ln * KID_LINE_CELLS + 1u + j;
+                                    const uint4 c = kid_load_cell(db.table, idx);
+                                    step[u]++;
+                                    if (c.x == (uint32_t)key[u] && c.y == (uint32_t)(key[u] >> 32)) { tgt[u] = c.z; slot[u] = idx; go = false; }
+                                } else if ((h.w >> 16) >= KID_HDR_FULL) {
+                                    ln = (ln + 1u) & db.line_mask;
+                                    h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
+                                    step[u]++;
+                                    m = kid_hdr_match(h, fp[u]);
+                                } else go = false;
+                            }
                         }
-                        any |= act[u];
+                    }
+                } else {
+                    uint64_t rp[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) rp[u] = 0;
+                    bool any = false;
+#pragma unroll
+                    for (int u = 0; u < U; u++) any |= act[u];
+                    while (any) {
+                        uint4 c[U];
+                        uint32_t idx[U];
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            idx[u] = (hlo[u] + (uint32_t)rp[u]) & db.slot_mask;
+                            c[u] = make_uint4(0, 0, 0, 0);
+                            if (act[u]) c[u] = kid_load_cell(db.table, idx[u]);
+                        }
+                        any = false;
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            if (act[u]) {
+                                step[u]++;
+                                rp[u] += step[u];
+                                if (c[u].z == 0) act[u] = false;
+                                else if (c[u].x == (uint32_t)key[u] && c[u].y == (uint32_t)(key[u] >> 32)) {
+                                    tgt[u] = c[u].z; slot[u] = idx[u]; act[u] = false;
+                                } else if (!(rp[u] < db.nslots) || (db.max_probes != 0 && step[u] >= db.max_probes)) act[u] = false;
+                            }
+                            any |= act[u];
+                        }
                     }
                 }
                 uint4 row[U];
@@ -567,26 +643,55 @@ __global__ void kid_trim_kernel(const uint8_t *quals, const uint64_t *offsets, u
 // word.  Like the reference there is no key comparison: duplicates take
 // separate cells.  Entries with target 0 are skipped: in the reference they
 // leave their cell "empty" (value == 0), i.e. invisible to every lookup.
-// probe sequence shared by both build passes: cell i of key's path in either geometry
-__device__ __forceinline__ uint32_t kid_path_first(uint64_t key, int k, uint32_t minloc, uint32_t slot_mask)
-{
-    return minloc ? kid_minloc_home(kid_minimizer_of_key(key, k), key, slot_mask) : ((uint32_t)kid_fmix64(key) & slot_mask);
-}
-
+// Pass 1: every entry claims a cell.  Reference geometry: the first free cell on the reference's
+// probe path (Hashtable::add_kmer, newkmer_10nx.cpp:235-263), claimed with a CAS on the ordinal
+// word; like the reference there is no key comparison, duplicates take separate cells.
+// Minimizer-localised geometry: the next free entry of the key's line (count in the header,
+// CAS), chaining into the following line when 7 entries are taken; the key's 16-bit fingerprint
+// goes into the header.  Entries with target 0 are skipped: in the reference they leave their
+// cell "empty" (value == 0), i.e. invisible to every lookup.
 __global__ void kid_build_insert_kernel(uint4 *table, uint32_t slot_mask, const uint64_t *keys, const uint32_t *targets,
-                                        uint64_t n, uint32_t ntar, unsigned long long *n_occupied, int k, uint32_t minloc)
+                                        uint64_t n, uint32_t ntar, unsigned long long *n_occupied, int k, uint32_t minloc,
+                                        uint32_t line_shift, uint32_t line_mask)
 {
     for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t t = targets[e];
         if (t == 0) continue;
         if (t >= ntar) { atomicAdd(n_occupied + 1, 1ull); continue; } // reported as KID_ERR_TARGET
         const uint64_t key = keys[e];
-        const uint32_t h = kid_path_first(key, k, minloc, slot_mask);
+        if (minloc) {
+            uint32_t line = kid_minloc_line(kid_minimizer_of_key(key, k), line_shift);
+            const uint32_t fp = kid_key_fp(key);
+            for (;;) {
+                uint32_t *hdr = reinterpret_cast<uint32_t *>(table + (uint64_t)line * KID_LINE_CELLS);
+                uint32_t old = __hip_atomic_load(hdr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t cnt;
+                for (;;) {
+                    cnt = old >> 16;
+                    if (cnt >= KID_HDR_FULL) break;
+                    const uint32_t seen = atomicCAS(hdr + 3, old, old + 0x10000u);
+                    if (seen == old) break;
+                    old = seen;
+                }
+                if (cnt < KID_LINE_ENTRIES) { // entry number cnt of this line is mine
+                    uint32_t *c = reinterpret_cast<uint32_t *>(table + (uint64_t)line * KID_LINE_CELLS + 1u + cnt);
+                    c[0] = (uint32_t)key;
+                    c[1] = (uint32_t)(key >> 32);
+                    c[2] = t;
+                    c[3] = (uint32_t)e + 1u;
+                    atomicOr(hdr + (cnt >> 1), fp << (16u * (cnt & 1u)));
+                    atomicAdd(n_occupied, 1ull);
+                    break;
+                }
+                line = (line + 1u) & line_mask; // cnt == 7 just became 8 (chain marker) or was 8 already
+            }
+            continue;
+        }
+        const uint32_t h = (uint32_t)kid_fmix64(key) & slot_mask;
         uint32_t rp = 0, i = 0;
         for (;;) {
             const uint32_t idx = (h + rp) & slot_mask;
-            ++i;
-            rp += minloc ? 1u : i;
+            rp += ++i;
             uint32_t *ordp = reinterpret_cast<uint32_t *>(table + idx) + 3;
             if (atomicCAS(ordp, 0u, (uint32_t)e + 1u) == 0u) {
                 uint32_t *c = reinterpret_cast<uint32_t *>(table + idx);
@@ -600,32 +705,51 @@ __global__ void kid_build_insert_kernel(uint4 *table, uint32_t slot_mask, const 
     }
 }
 
-// Pass 2: the reference's lookup returns the FIRST-inserted copy of a key
-// (earlier inserts sit earlier on the path).  Pass 1 placed duplicate copies
-// in arbitrary order, so every entry walks its path to the end of the chain,
-// finds the smallest ordinal among the cells holding its key and writes that
-// entry's target into the first such cell -- the only one a lookup can reach.
-// Key and ordinal words are immutable during this pass; only target words of
-// "first" cells are written, and all writers of one cell write the same value.
+// Pass 2: the reference's lookup returns the FIRST-inserted copy of a key (earlier inserts sit
+// earlier on the path).  Pass 1 placed duplicate copies in arbitrary order, so every entry walks
+// its whole chain in lookup order, finds the smallest ordinal among the cells holding its key and
+// writes that entry's target into the first such cell -- the only one a lookup can reach.
+// Key, ordinal and header words are immutable during this pass; only target words of "first"
+// cells are written, and all writers of one cell write the same value.
 __global__ void kid_build_firstwins_kernel(uint4 *table, uint32_t slot_mask, const uint64_t *keys, const uint32_t *targets,
-                                           uint64_t n, int k, uint32_t minloc)
+                                           uint64_t n, int k, uint32_t minloc, uint32_t line_shift, uint32_t line_mask)
 {
     for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
         if (targets[e] == 0 || table == nullptr) continue;
         const uint64_t key = keys[e];
-        const uint32_t h = kid_path_first(key, k, minloc, slot_mask);
-        uint32_t rp = 0, i = 0, first_idx = 0, min_ord = 0, copies = 0;
-        for (;;) {
-            const uint32_t idx = (h + rp) & slot_mask;
-            ++i;
-            rp += minloc ? 1u : i;
-            const uint32_t *c = reinterpret_cast<const uint32_t *>(table + idx);
-            const uint32_t ord = c[3];
-            if (ord == 0) break;
-            if (c[0] == (uint32_t)key && c[1] == (uint32_t)(key >> 32)) {
-                if (copies == 0) { first_idx = idx; min_ord = ord; }
-                else if (ord < min_ord) min_ord = ord;
-                copies++;
+        uint32_t first_idx = 0, min_ord = 0, copies = 0;
+        if (minloc) {
+            uint32_t line = kid_minloc_line(kid_minimizer_of_key(key, k), line_shift);
+            for (;;) {
+                const uint32_t base = line * KID_LINE_CELLS;
+                const uint32_t cnt = reinterpret_cast<const uint32_t *>(table + base)[3] >> 16;
+                const uint32_t ne = cnt < KID_LINE_ENTRIES ? cnt : KID_LINE_ENTRIES;
+                for (uint32_t j = 0; j < ne; j++) {
+                    const uint32_t *c = reinterpret_cast<const uint32_t *>(table + base + 1u + j);
+                    if (c[0] == (uint32_t)key && c[1] == (uint32_t)(key >> 32)) {
+                        const uint32_t ord = c[3];
+                        if (copies == 0) { first_idx = base + 1u + j; min_ord = ord; }
+                        else if (ord < min_ord) min_ord = ord;
+                        copies++;
+                    }
+                }
+                if (cnt < KID_HDR_FULL) break;
+                line = (line + 1u) & line_mask;
+            }
+        } else {
+            const uint32_t h = (uint32_t)kid_fmix64(key) & slot_mask;
+            uint32_t rp = 0, i = 0;
+            for (;;) {
+                const uint32_t idx = (h + rp) & slot_mask;
+                rp += ++i;
+                const uint32_t *c = reinterpret_cast<const uint32_t *>(table + idx);
+                const uint32_t ord = c[3];
+                if (ord == 0) break;
+                if (c[0] == (uint32_t)key && c[1] == (uint32_t)(key >> 32)) {
+                    if (copies == 0) { first_idx = idx; min_ord = ord; }
+                    else if (ord < min_ord) min_ord = ord;
+                    copies++;
+                }
             }
         }
         if (copies > 1) reinterpret_cast<uint32_t *>(table + first_idx)[2] = targets[min_ord - 1];

@@ -438,8 +438,11 @@ def test_crowded_table_and_heavy_minimizers():
     odb = oracle_db(parent, kk, tt, 14)
     q = np.concatenate([kk, fam ^ np.uint64(1), keys[11000:14000]])
     exp = odb.get(q)
-    for flags in (0, KID_FLAG_REF_GEOMETRY):
-        db = KmerDB(kk, tt, parent, k=K, log2_slots=14, flags=flags)
+    # (flags, log2_slots): the bucketed lines need <= 80 % load, so 2^14 falls back to the reference
+    # placement; at 2^15 the family of 3000 keys chains through hundreds of full lines
+    for flags, l2, geo in ((0, 14, 0), (KID_FLAG_REF_GEOMETRY, 14, 0), (0, 15, 1)):
+        db = KmerDB(kk, tt, parent, k=K, log2_slots=l2, flags=flags)
+        assert db.info.geometry == geo
         assert np.array_equal(db.lookup(q), exp)
         # reads made of the family k-mers back to back
         reads = []
