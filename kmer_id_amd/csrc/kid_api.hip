@@ -256,9 +256,9 @@ static int kid_db_build_common(const uint64_t *h_keys, const uint32_t *h_targets
     uint64_t n_occupied = 0;
     const bool host_build = (max_probes > 0) || (flags & KID_FLAG_HOST_BUILD);
     // minimizer-localised placement needs an unbounded probe loop (results must not depend on the
-    // cell geometry) and a window of 16 m-mers with 8 <= m <= 16
+    // cell geometry) and k >= 24 (minimizers of k - 14 >= 10 bases)
     // (7 of 8 cells hold entries, and chains need free lines: at most 80 % of the cells may be taken)
-    const uint32_t minloc = (!host_build && !(flags & KID_FLAG_REF_GEOMETRY) && k >= 23 && n <= (nslots / 10) * 8) ? 1u : 0u;
+    const uint32_t minloc = (!host_build && !(flags & KID_FLAG_REF_GEOMETRY) && k >= 24 && n <= (nslots / 10) * 8) ? 1u : 0u;
     const uint32_t line_bits = (uint32_t)log2_slots - 3u;
     const uint32_t line_shift = 32u - line_bits, line_mask = (uint32_t)((nslots >> 3) - 1);
     if (host_build) {

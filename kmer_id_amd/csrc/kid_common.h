@@ -70,15 +70,19 @@ KID_HD int kid_base_code(uint8_t c, bool u_is_t)
 // ---------------------------------------------------------------- minimizer-localised table geometry
 // The GPU-native table keeps the reference's 16-byte cells and its first-insert-wins lookup
 // results but places a key by the MINIMIZER of its k-mer: all k-mers that share their smallest
-// (hashed, strand-symmetric) m-mer, m = k - 15, go to one 128-byte line = 8 cells.  Consecutive
-// k-mers of a read share their minimizer for ~8.5 positions, so the lanes of a wavefront
-// (consecutive read positions) touch ~8 distinct lines per 64 lookups instead of 64 -- the
-// lookups coalesce.  Inside a line, cell 0 is a header {7 x 16-bit key fingerprints, count}:
-// one 16-byte load answers "absent" (99 % of all lookups) no matter how crowded the line is;
-// a fingerprint match costs one more load.  A full line (7 entries) chains into the next one.
+// (hashed, strand-symmetric) 16-mer go to one 128-byte line = 8 cells.  Consecutive k-mers of a
+// read share their minimizer for ~8 positions, so the lanes of a wavefront (consecutive read
+// positions) touch ~9 distinct lines per 64 lookups instead of 64 -- the lookups coalesce.
+// Inside a line, cell 0 is a header {7 x 16-bit key fingerprints, count}: one 16-byte load
+// answers "absent" (99 % of all lookups); a fingerprint match costs one more load.  A full line
+// (7 entries) chains into the next one; with 16-mers a minimizer owns < 1 DB key on average at
+// bact10 scale, so full lines are a 1e-5 event (with 15-mers ~3 % of the lookups met one).
 // Only legal where the probe loop is unbounded (newkmer_10nx, kmer_read_vf6): there the answer
 // depends on the key -> first target map alone, not on where cells sit.
-#define KID_MIN_W 16        // m-mers per k-mer window
+// minimizer length m and window w = k - m + 1 (m-mers per k-mer): w = 15 (16 for k = 31), the
+// two window sizes the 16-lane row scans of the kernel support; k = 30 -> m = 16 (32 bits)
+KID_HD int kid_min_window(int k) { return k >= 31 ? 16 : 15; }
+KID_HD int kid_min_mlen(int k) { return k - kid_min_window(k) + 1; }
 #define KID_LINE_CELLS 8    // header + 7 entries
 #define KID_LINE_ENTRIES 7
 #define KID_HDR_FULL 8u     // header count value: 7 entries stored and the chain continues in the next line
@@ -111,11 +115,11 @@ KID_HD uint32_t kid_mmer_hash(uint32_t f, int m)
 // minimizer of a whole k-mer given as its 2k-bit forward key (brute force: table build, unit lookups)
 KID_HD uint32_t kid_minimizer_of_key(uint64_t keyF, int k)
 {
-    const int m = k - (KID_MIN_W - 1);
+    const int w = kid_min_window(k), m = kid_min_mlen(k);
     const uint32_t mm = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
     uint32_t g = 0xFFFFFFFFu;
-    for (int j = 0; j < KID_MIN_W; j++) {
-        const uint32_t h = kid_mmer_hash((uint32_t)(keyF >> (2 * (KID_MIN_W - 1 - j))) & mm, m);
+    for (int j = 0; j < w; j++) {
+        const uint32_t h = kid_mmer_hash((uint32_t)(keyF >> (2 * (w - 1 - j))) & mm, m);
         g = h < g ? h : g;
     }
     return g;

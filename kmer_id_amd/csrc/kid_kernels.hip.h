@@ -91,23 +91,24 @@ struct KidSampleDev {
 
 // ------------------------------------------------------------------ hash lookup
 // Hashtable::getHash, newkmer_10nx.cpp:204-233 (+ probe cap kmer_read_m3.cpp:232)
-// exact per-halfword equality of the 7 header fingerprints with fp: bit j set = slot j matches
-__device__ __forceinline__ uint32_t kid_hdr_match(const uint4 &h, uint32_t fp)
+// Candidate entries of a line header for fingerprint fp, as a bit set: bit (15 - d) = entry 2d,
+// bit (31 - d) = entry 2d + 1 (d = header dword 0..3).  A superset of the true matches (the classic
+// zero-halfword test can also flag the upper half of a dword whose lower half matched); every
+// candidate is verified against the full key, so a false one only costs a load.
+__device__ __forceinline__ uint32_t kid_hdr_cand(const uint4 &h, uint32_t fp)
 {
-    const uint32_t rep = fp * 0x00010001u;
-    const uint32_t w[4] = {h.x ^ rep, h.y ^ rep, h.z ^ rep, (h.w ^ rep) | 0xFFFF0000u}; // upper half of .w is the count
-    uint32_t m = 0;
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-        // bit 15 / bit 31 set exactly where a halfword of w[d] is zero
-        const uint32_t z = ~(((w[d] & 0x7FFF7FFFu) + 0x7FFF7FFFu) | w[d] | 0x7FFF7FFFu);
-        m |= (((z >> 15) & 1u) | ((z >> 30) & 2u)) << (2 * d);
-    }
-    return m & 0x7Fu;
+    const uint32_t rep = fp * 0x00010001u, one = 0x00010001u, top = 0x80008000u;
+    const uint32_t a = h.x ^ rep, b = h.y ^ rep, c = h.z ^ rep, d = (h.w ^ rep) | 0xFFFF0000u; // upper half of .w = count
+    return (((a - one) & ~a) & top) | ((((b - one) & ~b) & top) >> 1) | ((((c - one) & ~c) & top) >> 2) |
+           ((((d - one) & ~d) & top) >> 3);
+}
+__device__ __forceinline__ uint32_t kid_cand_entry(uint32_t bit) // bit index from kid_hdr_cand -> entry 0..6
+{
+    return 2u * (15u - (bit & 15u)) + (bit >> 4);
 }
 
-// Lookup in the minimizer-localised table: header, then the cells whose fingerprint matches, then
-// the next line while the chain continues.  Returns the target (0 = absent); ncell = cells read.
+// Lookup in the minimizer-localised table: header, then the candidate entries, then the next line
+// while the chain continues.  Returns the target (0 = absent); ncell = cells read.
 __device__ __forceinline__ uint32_t kid_bucket_lookup(const KidDevDb &db, uint64_t key, uint32_t g, uint32_t &slot, uint32_t &ncell)
 {
     uint32_t line = kid_minloc_line(g, db.line_shift);
@@ -118,13 +119,13 @@ __device__ __forceinline__ uint32_t kid_bucket_lookup(const KidDevDb &db, uint64
         const uint32_t base = line * KID_LINE_CELLS;
         const uint4 h = db.table[base];
         ncell++;
-        uint32_t m = kid_hdr_match(h, fp);
+        uint32_t m = kid_hdr_cand(h, fp);
         while (m) {
-            const uint32_t j = (uint32_t)__builtin_ctz(m);
+            const uint32_t j = kid_cand_entry((uint32_t)__builtin_ctz(m));
             m &= m - 1;
             const uint4 c = db.table[base + 1u + j];
             ncell++;
-            if (c.x == (uint32_t)key && c.y == (uint32_t)(key >> 32)) { slot = base + 1u + j; return c.z; }
+            if (c.z != 0 && c.x == (uint32_t)key && c.y == (uint32_t)(key >> 32)) { slot = base + 1u + j; return c.z; }
         }
         if ((h.w >> 16) < KID_HDR_FULL) return 0;
         line = (line + 1u) & db.line_mask;
@@ -308,7 +309,8 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
     }
 
     const int k = db.k;
-    const int mlen = k - (KID_MIN_W - 1);
+    const uint32_t win = (uint32_t)kid_min_window(k); // m-mers per k-mer window: 15 or 16
+    const int mlen = kid_min_mlen(k);
     const uint64_t gw = (uint64_t)blockIdx.x * wpb + wib;
     const uint64_t nw = (uint64_t)gridDim.x * wpb;
     uint32_t n_lookups = 0, n_probes = 0;  // per lane, per workgroup-lifetime: far below 2^32
@@ -421,15 +423,19 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
                         P[j] = kid_row_prefix_min(h);
                         if (j < U) S[j] = kid_row_suffix_min(h);
                     }
-                    // ... and their minimum over every window of 16: min(a[p..p+15]) = min(S[p], P[p+15])
-                    const uint32_t src = (lane + 15u) & 63u;
+                    // ... and their minimum over every window a[p..p+win-1].  With q = p mod 16: the window
+                    // leaves its 16-lane row iff q + win > 16, then it is min(S[p], P[p+win-1]); inside
+                    // one row it is exactly the prefix P[p+win-1] (q = 0) or the suffix S[p] (win = 15, q = 1)
+                    const uint32_t src = (lane + win - 1u) & 63u;
+                    const uint32_t q16 = lane & 15u;
                     uint32_t nxt = (uint32_t)__shfl((int)P[0], (int)src);
 #pragma unroll
                     for (int u = 0; u < U; u++) {
                         const uint32_t same = nxt;
                         nxt = (uint32_t)__shfl((int)P[u + 1], (int)src);
-                        const uint32_t pn = (lane + 15u < 64u) ? same : nxt;
-                        hlo[u] = S[u] < pn ? S[u] : pn;
+                        const uint32_t pn = (lane + win - 1u < 64u) ? same : nxt;
+                        const uint32_t both = S[u] < pn ? S[u] : pn;
+                        hlo[u] = (q16 + win > 16u) ? both : (q16 == 0u ? pn : S[u]);
                     }
                 }
                 uint32_t tgt[U], slot[U], step[U];
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
 #pragma unroll
                     for (int u = 0; u < U; u++) {
                         fp[u] = kid_key_fp(key[u]);
-                        mm[u] = act[u] ? kid_hdr_match(hd[u], fp[u]) : 0u;
+                        mm[u] = act[u] ? kid_hdr_cand(hd[u], fp[u]) : 0u;
                         step[u] = act[u] ? 1u : 0u;
                         more |= act[u] && (mm[u] != 0 || (hd[u].w >> 16) >= KID_HDR_FULL);
                     }
@@ -462,17 +468,17 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
                             uint32_t m = mm[u], ln = line[u];
                             while (go) {
                                 if (m) {
-                                    const uint32_t j = (uint32_t)__builtin_ctz(m);
+                                    const uint32_t j = kid_cand_entry((uint32_t)__builtin_ctz(m));
                                     m &= m - 1;
                                     const uint32_t idx = ln * KID_LINE_CELLS + 1u + j;
                                     const uint4 c = kid_load_cell(db.table, idx);
                                     step[u]++;
-                                    if (c.x == (uint32_t)key[u] && c.y == (uint32_t)(key[u] >> 32)) { tgt[u] = c.z; slot[u] = idx; go = false; }
+                                    if (c.z != 0 && c.x == (uint32_t)key[u] && c.y == (uint32_t)(key[u] >> 32)) { tgt[u] = c.z; slot[u] = idx; go = false; }
                                 } else if ((h.w >> 16) >= KID_HDR_FULL) {
                                     ln = (ln + 1u) & db.line_mask;
                                     h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
                                     step[u]++;
-                                    m = kid_hdr_match(h, fp[u]);
+                                    m = kid_hdr_cand(h, fp[u]);
                                 } else go = false;
                             }
                         }
@@ -707,17 +713,18 @@ __global__ void kid_build_insert_kernel(uint4 *table, uint32_t slot_mask, const 
 
 // Pass 2: the reference's lookup returns the FIRST-inserted copy of a key (earlier inserts sit
 // earlier on the path).  Pass 1 placed duplicate copies in arbitrary order, so every entry walks
-// its whole chain in lookup order, finds the smallest ordinal among the cells holding its key and
-// writes that entry's target into the first such cell -- the only one a lookup can reach.
-// Key, ordinal and header words are immutable during this pass; only target words of "first"
-// cells are written, and all writers of one cell write the same value.
+// its whole chain, finds the smallest ordinal among the cells holding its key and writes that
+// entry's target into ITS OWN cell: afterwards every copy carries the first insert's target and it
+// does not matter which copy a lookup meets first (it always meets the same one, so the seen-bit
+// of a key is unique too).  Keys, ordinals and headers are immutable here; each thread writes only
+// the target word of its own cell.
 __global__ void kid_build_firstwins_kernel(uint4 *table, uint32_t slot_mask, const uint64_t *keys, const uint32_t *targets,
                                            uint64_t n, int k, uint32_t minloc, uint32_t line_shift, uint32_t line_mask)
 {
     for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
         if (targets[e] == 0 || table == nullptr) continue;
         const uint64_t key = keys[e];
-        uint32_t first_idx = 0, min_ord = 0, copies = 0;
+        uint32_t my_idx = 0, min_ord = 0xFFFFFFFFu, copies = 0;
         if (minloc) {
             uint32_t line = kid_minloc_line(kid_minimizer_of_key(key, k), line_shift);
             for (;;) {
@@ -728,8 +735,8 @@ __global__ void kid_build_firstwins_kernel(uint4 *table, uint32_t slot_mask, con
                     const uint32_t *c = reinterpret_cast<const uint32_t *>(table + base + 1u + j);
                     if (c[0] == (uint32_t)key && c[1] == (uint32_t)(key >> 32)) {
                         const uint32_t ord = c[3];
-                        if (copies == 0) { first_idx = base + 1u + j; min_ord = ord; }
-                        else if (ord < min_ord) min_ord = ord;
+                        if (ord == (uint32_t)e + 1u) my_idx = base + 1u + j;
+                        min_ord = ord < min_ord ? ord : min_ord;
                         copies++;
                     }
                 }
@@ -746,13 +753,13 @@ __global__ void kid_build_firstwins_kernel(uint4 *table, uint32_t slot_mask, con
                 const uint32_t ord = c[3];
                 if (ord == 0) break;
                 if (c[0] == (uint32_t)key && c[1] == (uint32_t)(key >> 32)) {
-                    if (copies == 0) { first_idx = idx; min_ord = ord; }
-                    else if (ord < min_ord) min_ord = ord;
+                    if (ord == (uint32_t)e + 1u) my_idx = idx;
+                    min_ord = ord < min_ord ? ord : min_ord;
                     copies++;
                 }
             }
         }
-        if (copies > 1) reinterpret_cast<uint32_t *>(table + first_idx)[2] = targets[min_ord - 1];
+        if (copies > 1 && min_ord != (uint32_t)e + 1u) reinterpret_cast<uint32_t *>(table + my_idx)[2] = targets[min_ord - 1];
     }
 }
 
