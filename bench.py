@@ -103,6 +103,21 @@ def cpu_baseline(host_keys, parent, cum, log2_slots, n_reads):
                       "%.2f M lookups/s" % (n_reads, n_reads // 2, keys.size, log2_slots, sec, build_s, st["lookups"] / sec / 1e6)}, (g, u)
 
 
+def traffic_from_profile(args, info):
+    """HBM bytes per classify launch from the committed rocprofv3 counter passes (profiles/):
+    TCC_EA0_RDREQ_128B x 128 B + 64-byte requests + WRITE_SIZE.  Only reported when the profile
+    was taken on this exact workload; the live run does not collect counters."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_final.json")
+    if not os.path.exists(path) or args.scale != 1.0 or args.pairs != 1_000_000 or args.log2_slots != 30 or args.geometry != "minloc":
+        return None
+    try:
+        d = json.load(open(path))
+        rd = d["TCC_EA0_RDREQ_128B_sum"]["avg"] * 128 + d["TCC_EA0_RDREQ_64B_sum"]["avg"] * 64 + d["TCC_EA0_RDREQ_32B_sum"]["avg"] * 32
+        return rd + d["WRITE_SIZE"]["avg"] * 1024
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,7 +281,7 @@ def main():
                        "db_scale": args.scale, "pairs_per_gpu_per_step": args.pairs, "read_len": READ_LEN, "k": K,
                        "sharding": "reads sharded over %d rank(s), DB replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic_from_profile(args, info),
                          "kernel": "kid_classify_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": probes_per_launch * 16,
                          "lookups_per_launch": st["lookups"] / args.steps, "probes_per_launch": probes_per_launch,

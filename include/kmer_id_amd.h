@@ -150,7 +150,8 @@ int kid_sample_seen_bytes(const kid_sample *s, uint64_t *nbytes);
 int kid_sample_seen_export(kid_sample *s, uint64_t byte_off, uint64_t nbytes, void *dst, int dst_on_device);
 int kid_sample_seen_or(kid_sample *s, uint64_t byte_off, uint64_t nbytes, const void *src, int src_on_device);
 int kid_sample_gcount(kid_sample *s, int64_t *gcount);
-/* ucount contribution of the table cells [slot_begin, slot_end) */
+/* ucount contribution of the table cells [slot_begin, slot_end) (multiples of 128; byte ranges of
+ * the bitmap helpers above are multiples of 16) */
 int kid_sample_ucount_range(kid_sample *s, uint64_t slot_begin, uint64_t slot_end, int64_t *ucount);
 
 /* ---- synthetic workload generators (bench + tests; deterministic, seeded) ------

@@ -462,7 +462,7 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
     kid_sample *s = new kid_sample();
     s->db = db;
     const size_t nt = (size_t)db->info.ntar;
-    s->seen_words = (db->d.nslots + 31) / 32;
+    s->seen_words = ((db->d.nslots + 127) / 128) * 4; // whole 16-byte groups (128 cells)
 #define KID_S_HIP(call)                                                                                           \
     do {                                                                                                          \
         hipError_t e_ = (call);                                                                                   \
@@ -694,8 +694,9 @@ extern "C" int kid_sample_gcount(kid_sample *s, int64_t *gcount)
 extern "C" int kid_sample_ucount_range(kid_sample *s, uint64_t slot_begin, uint64_t slot_end, int64_t *ucount)
 {
     if (!s || !ucount) return kid_fail(KID_ERR_ARG, "null argument");
-    if (slot_begin > slot_end || slot_end > s->db->d.nslots || (slot_begin & 31) || (slot_end & 31))
-        return kid_fail(KID_ERR_ARG, "slot range must be 32-aligned and inside the table");
+    if (slot_end == s->db->d.nslots) slot_end = s->seen_words * 32; // tables smaller than one group: count the padding too (always 0)
+    if (slot_begin > slot_end || slot_end > s->seen_words * 32 || (slot_begin & 127) || (slot_end & 127))
+        return kid_fail(KID_ERR_ARG, "slot range must be 128-aligned and inside the table");
     int rc = kid_use_device(s->db->device);
     if (rc != KID_OK) return rc;
     KID_HIP(hipDeviceSynchronize());
@@ -703,8 +704,14 @@ extern "C" int kid_sample_ucount_range(kid_sample *s, uint64_t slot_begin, uint6
     KID_HIP(hipMemset(s->ucount, 0, nt * 8));
     const uint64_t w0 = slot_begin / 32, w1 = slot_end / 32;
     if (w1 > w0) {
-        hipLaunchKernelGGL(kid_ucount_kernel, dim3(kid_grid_for(w1 - w0, 256, s->db->num_cu * 16)), dim3(256), 0, 0, s->seen, w0,
-                           w1, s->db->table, s->ucount);
+        const uint32_t ntar = (uint32_t)s->db->info.ntar;
+        const int ugrid = kid_grid_for((w1 - w0) / 4, 512, s->db->num_cu * 4);
+        if (ntar * 4u <= 64u * 1024u)
+            hipLaunchKernelGGL((kid_ucount_kernel<true>), dim3(ugrid), dim3(512), ntar * 4u, 0, s->seen, w0, w1, s->db->table,
+                               s->ucount, ntar);
+        else
+            hipLaunchKernelGGL((kid_ucount_kernel<false>), dim3(ugrid), dim3(512), 0, 0, s->seen, w0, w1, s->db->table, s->ucount,
+                               ntar);
         KID_HIP(hipGetLastError());
     }
     KID_HIP(hipDeviceSynchronize());
@@ -753,8 +760,8 @@ extern "C" int kid_sample_seen_export(kid_sample *s, uint64_t byte_off, uint64_t
 extern "C" int kid_sample_seen_or(kid_sample *s, uint64_t byte_off, uint64_t nbytes, const void *src, int src_on_device)
 {
     if (!s || (nbytes && !src)) return kid_fail(KID_ERR_ARG, "null argument");
-    if ((byte_off & 3) || (nbytes & 3) || byte_off + nbytes > s->seen_words * 4)
-        return kid_fail(KID_ERR_ARG, "range must be 4-byte aligned and inside the bitmap");
+    if ((byte_off & 15) || (nbytes & 15) || byte_off + nbytes > s->seen_words * 4)
+        return kid_fail(KID_ERR_ARG, "range must be 16-byte aligned and inside the bitmap");
     int rc = kid_use_device(s->db->device);
     if (rc != KID_OK) return rc;
     if (nbytes == 0) return KID_OK;

@@ -766,16 +766,40 @@ __global__ void kid_build_firstwins_kernel(uint4 *table, uint32_t slot_mask, con
 // ------------------------------------------------------------------ ucount from the seen-bitmap
 // ucount[t] = number of distinct DB k-mers of target t seen in the sample
 // (newkmer_10nx.cpp:596-603), counted over the cells [w_begin*32, w_end*32)
+template <bool HIST>
 __global__ void kid_ucount_kernel(const uint32_t *seen, uint64_t w_begin, uint64_t w_end, const uint4 *table,
-                                  unsigned long long *ucount)
+                                  unsigned long long *ucount, uint32_t ntar)
 {
-    for (uint64_t w = w_begin + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < w_end; w += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t bits = seen[w];
-        while (bits) {
-            const uint32_t bpos = (uint32_t)__builtin_ctz(bits);
-            bits &= bits - 1;
-            const uint32_t t = table[w * 32ull + bpos].z;
-            atomicAdd(&ucount[t], 1ull);
+    // the bitmap is almost empty: stream it 16 bytes per lane and only look inside non-zero words;
+    // counts go to a per-workgroup LDS histogram first (millions of hits land on a few thousand targets)
+    extern __shared__ uint32_t kid_uhist[];
+    if (HIST) {
+        for (uint32_t i = threadIdx.x; i < ntar; i += blockDim.x) kid_uhist[i] = 0;
+        __syncthreads();
+    }
+    const uint64_t q_begin = w_begin >> 2, q_end = w_end >> 2; // callers pass 128-cell aligned ranges
+    const uint4 *seen4 = reinterpret_cast<const uint4 *>(seen);
+    for (uint64_t q = q_begin + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < q_end; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 v = seen4[q];
+        if ((v.x | v.y | v.z | v.w) == 0) continue;
+        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t bits = words[i];
+            while (bits) {
+                const uint32_t bpos = (uint32_t)__builtin_ctz(bits);
+                bits &= bits - 1;
+                const uint32_t t = table[(q * 4ull + (uint64_t)i) * 32ull + bpos].z;
+                if (HIST) atomicAdd(&kid_uhist[t], 1u);
+                else atomicAdd(&ucount[t], 1ull);
+            }
+        }
+    }
+    if (HIST) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < ntar; i += blockDim.x) {
+            const uint32_t c = kid_uhist[i];
+            if (c) atomicAdd(&ucount[i], (unsigned long long)c);
         }
     }
 }

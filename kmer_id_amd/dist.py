@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 
-def merge_counts(gcount, seen, count_slice, group=None):
+def merge_counts(gcount, seen, count_slice, group=None, force_collectives=False):
     """gcount: int64[ntar] tensor; seen: uint8[nbytes] tensor (this rank's bitmap), both on the
     backend's device.  count_slice(byte_begin, byte_end, merged_slice_uint8) -> int64[ntar]
     tensor with the ucount contribution of that slice of table cells.
@@ -25,10 +25,10 @@ def merge_counts(gcount, seen, count_slice, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     nbytes = seen.numel()
-    if world == 1:
+    if world == 1 and not force_collectives:
         return gcount.clone(), count_slice(0, nbytes, seen)
-    if nbytes % (world * 4) != 0:
-        raise ValueError("bitmap of %d bytes does not split into %d 4-byte aligned slices" % (nbytes, world))
+    if nbytes % (world * 16) != 0:
+        raise ValueError("bitmap of %d bytes does not split into %d 16-byte aligned slices" % (nbytes, world))
     sl = nbytes // world
     recv = torch.empty_like(seen)
     dist.all_to_all_single(recv, seen, group=group)  # chunk j of recv = slice `rank` of rank j's bitmap
@@ -39,7 +39,7 @@ def merge_counts(gcount, seen, count_slice, group=None):
     return both[0], both[1]
 
 
-def merge_sample(sample, device, group=None):
+def merge_sample(sample, device, group=None, force_collectives=False):
     """Sample-level wrapper for the HIP path: -> (gcount, ucount) numpy int64 arrays."""
     ntar = sample.ntar
     g = torch.from_numpy(sample.gcount()).to(device)
@@ -52,5 +52,5 @@ def merge_sample(sample, device, group=None):
             sample.seen_or(b0, merged.data_ptr(), nbytes=b1 - b0, on_device=True)
         return torch.from_numpy(sample.ucount_range(b0 * 8, b1 * 8)).to(device)
 
-    gt, ut = merge_counts(g, seen, count_slice, group)
+    gt, ut = merge_counts(g, seen, count_slice, group, force_collectives)
     return gt.cpu().numpy().astype(np.int64), ut.cpu().numpy().astype(np.int64)

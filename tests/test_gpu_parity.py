@@ -471,3 +471,55 @@ def test_table_full_and_bad_inputs():
     with pytest.raises(kmer_id_amd.KidError) as e:
         KmerDB(keys[:10], np.full(10, 6000, np.uint32), parent, log2_slots=10)
     assert e.value.status == -7
+
+
+def test_seen_bitmap_export_or_and_ranges(seeded):
+    """the multi-GPU merge primitives on one GPU: two shards of a sample, merged by hand, must equal
+    the unsharded sample (ucount is not additive, the OR of the seen bitmaps is)"""
+    parent, cum, keys, targets, odb, db = seeded
+    n, L = 12000, 150
+    bases = synth.reads(cum, parent, n, L, K, r0=4242)
+    off = synth.fixed_offsets(n, L)
+    whole = db.sample(); whole.classify(bases, off, want_final=False)
+    g, u = whole.end()
+    a = db.sample(); a.classify(bases, off[:n // 2 + 1], want_final=False)
+    b = db.sample(); b.classify(bases, off[n // 2:], want_final=False)
+    ga, ua = a.end(); gb, ub = b.end()
+    assert np.array_equal(ga + gb, g)
+    assert (ua + ub).sum() > u.sum()          # double counting if one simply adds
+    nbytes = a.seen_bytes()
+    assert nbytes == b.seen_bytes() and nbytes % 16 == 0
+    half = (nbytes // 2) & ~15
+    # rank 0 owns [0, half), rank 1 owns [half, nbytes): OR the peer's slice in, count the own slice
+    a.seen_or(0, b.seen_export(0, half))
+    b.seen_or(half, a.seen_export(half, nbytes - half))
+    u0 = a.ucount_range(0, half * 8)
+    u1 = b.ucount_range(half * 8, nbytes * 8)
+    assert np.array_equal(u0 + u1, u)
+    for s_ in (whole, a, b):
+        s_.close()
+
+
+def test_merge_sample_over_rccl_single_rank(seeded):
+    """kmer_id_amd.dist.merge_sample with the collectives forced on (world size 1, backend nccl = RCCL)"""
+    import os
+    import torch
+    import torch.distributed as dist
+    from kmer_id_amd.dist import merge_sample
+    parent, cum, keys, targets, odb, db = seeded
+    n, L = 6000, 150
+    bases = synth.reads(cum, parent, n, L, K, r0=99)
+    s = db.sample(); s.classify(bases, synth.fixed_offsets(n, L), want_final=False)
+    g, u = s.end()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        gm, um = merge_sample(s, torch.device("cuda", 0), force_collectives=True)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert np.array_equal(gm, g) and np.array_equal(um, u)
+    s.close()
