@@ -14,6 +14,8 @@ HOST = os.path.join(HERE, "host")
 LIB = os.path.join(HERE, "libkmer_id_amd.so")
 BIN_DIR = os.path.join(HERE, "bin")
 NK10 = os.path.join(BIN_DIR, "nk10")
+# front-end -> its main file; everything else under host/ is shared
+FRONT_ENDS = {"nk10": "nk10_main.cpp", "kmer_read_vf6": "vf6_main.cpp", "kmer_read_m3": "m3_main.cpp"}
 
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-value", "-Wno-unused-result"]
 
@@ -56,19 +58,29 @@ def host_sources():
 def build_cli(force=False, verbose=False):
     """nk10: the reference-compatible command line program (host C++ over the C ABI)."""
     srcs = host_sources()
-    cpps = [s for s in srcs if s.endswith(".cpp")]
-    if not cpps:
+    mains = set(FRONT_ENDS.values())
+    shared = [s for s in srcs if s.endswith(".cpp") and os.path.basename(s) not in mains]
+    if not shared:
         return None
     build_library(force=force, verbose=verbose)
     os.makedirs(BIN_DIR, exist_ok=True)
-    if force or _newer(NK10, srcs + [LIB]):
-        cxx = shutil.which("g++") or "g++"
-        cmd = [cxx, "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", NK10] + cpps + [
-            "-L", HERE, "-lkmer_id_amd", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    cxx = shutil.which("g++") or "g++"
+    for name, main in FRONT_ENDS.items():
+        main_path = os.path.join(HOST, main)
+        if not os.path.exists(main_path):
+            continue
+        out = os.path.join(BIN_DIR, name)
+        if force or _newer(out, srcs + [LIB]):
+            cmd = [cxx, "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", out, main_path] + shared + [
+                "-L", HERE, "-lkmer_id_amd", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
     return NK10
+
+
+def cli_path(name):
+    return os.path.join(BIN_DIR, name)
 
 
 def build_oracle(verbose=False):

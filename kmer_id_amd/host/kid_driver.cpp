@@ -1,0 +1,134 @@
+#include "kid_driver.h"
+
+#include <stdlib.h>
+
+#include <condition_variable>
+#include <deque>
+#include <iostream>
+#include <mutex>
+#include <thread>
+
+namespace kidhost {
+
+void die_kid(int rc)
+{
+    std::cerr << "kmer_id_amd: " << kid_strerror(rc) << ": " << kid_last_error() << "\n";
+    exit(rc == KID_ERR_TABLE_FULL ? 1 : 3);
+}
+
+Engine::~Engine()
+{
+    if (sample) kid_sample_destroy(sample);
+    if (db) kid_db_destroy(db);
+}
+
+bool engine_open(Engine &e, const ProbeSet &ps, const std::vector<int32_t> &parent, int k, int log2_slots, int max_probes,
+                 unsigned flags, int device)
+{
+    e.ntar = (int)parent.size();
+    e.k = k;
+    int rc = kid_db_build(ps.keys.data(), ps.targets.data(), ps.keys.size(), parent.data(), e.ntar, k, log2_slots, max_probes,
+                          flags, device, &e.db);
+    if (rc == KID_ERR_TABLE_FULL) return false;
+    if (rc != KID_OK) die_kid(rc);
+    rc = kid_sample_begin(e.db, &e.sample);
+    if (rc != KID_OK) die_kid(rc);
+    return true;
+}
+
+namespace {
+struct Pipe { // bounded hand-off of parsed batches from the reader thread to the GPU thread
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::unique_ptr<ReadBatch>> q;
+    bool done = false;
+    bool failed = false;
+    Fatal failure{0, ""};
+};
+}
+
+long long run_source(Engine &e, const std::function<std::unique_ptr<ReadSource>()> &open_source, ReadSaver &saver)
+{
+    Pipe pipe;
+    std::thread reader([&]() {
+        try {
+            std::unique_ptr<ReadSource> src = open_source();
+            if (src) {
+                for (;;) {
+                    std::unique_ptr<ReadBatch> b(new ReadBatch());
+                    if (!src->fill(*b, e.batch_reads, e.batch_bases)) break;
+                    std::unique_lock<std::mutex> lk(pipe.m);
+                    pipe.cv.wait(lk, [&] { return pipe.q.size() < 3; });
+                    pipe.q.push_back(std::move(b));
+                    pipe.cv.notify_all();
+                }
+                src->close();
+            }
+        } catch (const Fatal &f) {
+            std::lock_guard<std::mutex> lk(pipe.m);
+            pipe.failed = true;
+            pipe.failure = f;
+        }
+        std::lock_guard<std::mutex> lk(pipe.m);
+        pipe.done = true;
+        pipe.cv.notify_all();
+    });
+    long long n = 0;
+    std::vector<uint32_t> final_targ;
+    int rc = KID_OK;
+    for (;;) {
+        std::unique_ptr<ReadBatch> b;
+        {
+            std::unique_lock<std::mutex> lk(pipe.m);
+            pipe.cv.wait(lk, [&] { return !pipe.q.empty() || pipe.done; });
+            if (pipe.q.empty()) break;
+            b = std::move(pipe.q.front());
+            pipe.q.pop_front();
+            pipe.cv.notify_all();
+        }
+        if (rc != KID_OK) continue; // drain
+        final_targ.resize(b->size());
+        rc = kid_classify_batch(e.sample, b->bases.data(), b->offsets.data(), b->start.data(), b->stop.data(), b->size(),
+                                final_targ.data());
+        if (rc == KID_OK) {
+            saver.add_batch(*b, final_targ);
+            n += (long long)b->size();
+        }
+    }
+    reader.join();
+    if (rc != KID_OK) die_kid(rc);
+    if (pipe.failed) throw pipe.failure; // reads parsed before the failure were processed, as in the reference
+    return n;
+}
+
+void dry_dump_db(FILE *f, const std::vector<int32_t> &parent, const ProbeSet &ps)
+{
+    fprintf(f, "PARENT %zu\n", parent.size());
+    for (size_t i = 0; i < parent.size(); i++)
+        if (parent[i] != 1) fprintf(f, "%zu %d\n", i, parent[i]);
+    fprintf(f, "PROBES %zu %lld\n", ps.keys.size(), ps.lines_parsed);
+    for (size_t i = 0; i < ps.keys.size(); i++) fprintf(f, "%llu %u\n", (unsigned long long)ps.keys[i], ps.targets[i]);
+}
+
+void dry_dump_source(FILE *f, const std::string &label, ReadSource &src, size_t batch_reads)
+{
+    ReadBatch b;
+    fprintf(f, "FILE %s\n", label.c_str());
+    while (src.fill(b, batch_reads, (size_t)-1))
+        for (size_t r = 0; r < b.size(); r++) {
+            fprintf(f, "%s\t%d\t%d\t", b.acc[r].c_str(), b.start[r], b.stop[r]);
+            fwrite(b.bases.data() + b.offsets[r], 1, (size_t)(b.offsets[r + 1] - b.offsets[r]), f);
+            fputc('\n', f);
+        }
+    src.close();
+}
+
+void finish_sample(Engine &e, const std::string &result_path)
+{
+    std::vector<int64_t> g((size_t)e.ntar), u((size_t)e.ntar);
+    int rc = kid_sample_end(e.sample, g.data(), u.data());
+    if (rc != KID_OK) die_kid(rc);
+    write_result(result_path, g, u);
+}
+
+} // namespace kidhost

@@ -1,0 +1,41 @@
+// kid_driver.h -- what the three front-ends (nk10, kmer_read_vf6, kmer_read_m3) share: the database
+// on the GPU, the reader-thread / GPU-thread pipeline over one input file, closing a sample.
+#pragma once
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kid_host.h"
+#include "kmer_id_amd.h"
+
+namespace kidhost {
+
+struct Engine {
+    kid_db *db = nullptr;
+    kid_sample *sample = nullptr;
+    int ntar = 0, k = 30;
+    size_t batch_reads = 1 << 20;
+    size_t batch_bases = 256u << 20;
+    ~Engine();
+};
+
+[[noreturn]] void die_kid(int rc);
+
+// Hashtable + Tree1 onto the GPU.  Returns false where the reference prints "out of memory in table"
+// and exits with 1 (newkmer_10nx.cpp:256-260).
+bool engine_open(Engine &e, const ProbeSet &ps, const std::vector<int32_t> &parent, int k, int log2_slots, int max_probes,
+                 unsigned flags, int device);
+
+// one input file: parse (+ trim) on a reader thread, classify batch by batch on the caller's thread.
+// Returns the number of reads handed to process_read (the reference's tct increment).
+long long run_source(Engine &e, const std::function<std::unique_ptr<ReadSource>()> &open_source, ReadSaver &saver);
+
+// --dry-run support (host stages only, no GPU): what WOULD be handed to the GPU, as text
+void dry_dump_db(FILE *f, const std::vector<int32_t> &parent, const ProbeSet &ps);
+void dry_dump_source(FILE *f, const std::string &label, ReadSource &src, size_t batch_reads);
+
+// gcount / ucount of the sample -> "<i>,<g>,<u>" lines
+void finish_sample(Engine &e, const std::string &result_path);
+
+} // namespace kidhost

@@ -214,13 +214,13 @@ bool trim_read(const std::string &seq, const std::string &qual, int k, int &star
 // ---------------------------------------------------------------- FASTQ stream
 FastqStream::FastqStream(const std::string &path, int k) : lines_(path), k_(k) {}
 
-bool FastqStream::fill(ReadBatch &out, size_t max_reads)
+bool FastqStream::fill(ReadBatch &out, size_t max_reads, size_t max_bases)
 {
     out.clear();
     const char *line;
     size_t len;
     std::string qual;
-    while (out.size() < max_reads && lines_.next(line, len)) {
+    while (out.size() < max_reads && out.bases.size() < max_bases && lines_.next(line, len)) {
         if (len == 0) continue; // blank lines do not advance the record phase (:788)
         if (mod4_ == 1) seq_.assign(line, len);
         else if (mod4_ == 0) acc_.assign(line, len);
@@ -240,6 +240,99 @@ bool FastqStream::fill(ReadBatch &out, size_t max_reads)
     return out.size() > 0;
 }
 
+// ---------------------------------------------------------------- FASTA(.gz)
+FastaGzStream::FastaGzStream(const std::string &path, int k) : lines_(path), k_(k) {}
+
+static void push_whole_read(ReadBatch &out, const std::string &seq, const std::string &acc)
+{
+    out.bases.insert(out.bases.end(), seq.begin(), seq.end());
+    out.offsets.push_back(out.bases.size());
+    out.start.push_back(0);
+    out.stop.push_back((int32_t)seq.size() - 1);
+    out.acc.push_back(acc);
+}
+
+bool FastaGzStream::fill(ReadBatch &out, size_t max_reads, size_t max_bases)
+{
+    out.clear();
+    if (eof_) return false;
+    const char *line;
+    size_t len;
+    while (out.size() < max_reads && out.bases.size() < max_bases) {
+        if (!lines_.next(line, len)) {
+            eof_ = true;
+            if ((int)seq_.length() > k_) push_whole_read(out, seq_, acc_); // the last record (:867-870)
+            seq_.clear();
+            break;
+        }
+        if (len == 0) continue;
+        if (line[0] == '>') {
+            if ((int)seq_.length() > k_) push_whole_read(out, seq_, acc_); // :849-852
+            seq_.clear();
+            acc_.assign(line + 1, len - 1);
+        } else {
+            seq_.append(line, len);
+        }
+    }
+    return out.size() > 0;
+}
+
+// ---------------------------------------------------------------- plain FASTA / FASTQ
+struct PlainTokenStream::Impl {
+    std::ifstream fin;
+};
+
+PlainTokenStream::PlainTokenStream(const std::string &path, int k, bool fastq) : impl_(new Impl()), k_(k), fastq_(fastq)
+{
+    impl_->fin.open(path);
+    open_ = (bool)impl_->fin;
+}
+
+bool PlainTokenStream::fill(ReadBatch &out, size_t max_reads, size_t max_bases)
+{
+    out.clear();
+    if (!open_ || eof_) return false;
+    std::string line;
+    while (out.size() < max_reads && out.bases.size() < max_bases) {
+        if (!std::getline(impl_->fin, line)) {
+            eof_ = true;
+            if (!fastq_ && (int)seq_.length() > k_) push_whole_read(out, seq_, acc_);
+            seq_.clear();
+            break;
+        }
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        // the reference's own extraction: a line without a token leaves lseq_ as it was
+        std::stringstream ls(line);
+        ls >> lseq_;
+        if (fastq_) {
+            if (lseq_.length() > 0) {
+                if (mod4_ == 1) seq_ = lseq_;
+                else if (mod4_ == 0) acc_ = lseq_;
+                else if (mod4_ == 3) {
+                    int st, sp;
+                    if (trim_read(seq_, lseq_, k_, st, sp)) {
+                        out.bases.insert(out.bases.end(), seq_.begin(), seq_.end());
+                        out.offsets.push_back(out.bases.size());
+                        out.start.push_back(st);
+                        out.stop.push_back(sp);
+                        out.acc.push_back(acc_);
+                    }
+                }
+                mod4_ = (mod4_ + 1) % 4;
+            }
+        } else {
+            if (!lseq_.empty() && lseq_[0] == '>') {
+                if ((int)seq_.length() > k_) push_whole_read(out, seq_, acc_);
+                seq_.clear();
+                acc_ = lseq_.substr(1);
+            } else {
+                seq_ += lseq_;
+            }
+        }
+    }
+    return out.size() > 0;
+}
+
 // ---------------------------------------------------------------- outputs
 void write_result(const std::string &path, const std::vector<int64_t> &gcount, const std::vector<int64_t> &ucount)
 {
@@ -249,28 +342,36 @@ void write_result(const std::string &path, const std::vector<int64_t> &gcount, c
     fclose(f);
 }
 
-ReadSaver::ReadSaver(const std::string &path, int ntar) : seen_((size_t)ntar, 0)
+ReadSaver::ReadSaver(const std::string &first12_path, int ntar, const std::string &target_path, uint32_t save_target,
+                     bool first12_enabled)
+    : save_target_(save_target), first12_enabled_(first12_enabled), seen_((size_t)ntar, 0)
 {
-    f_ = fopen(path.c_str(), "w"); // ofstream::trunc, :1025
+    if (!first12_path.empty()) f_ = fopen(first12_path.c_str(), "w"); // ofstream::trunc, :1025
+    if (!target_path.empty()) f2_ = fopen(target_path.c_str(), "w");
 }
 
 ReadSaver::~ReadSaver()
 {
     if (f_) fclose(f_);
+    if (f2_) fclose(f2_);
+}
+
+static void write_saved(FILE *f, uint32_t t, const ReadBatch &b, size_t r)
+{
+    const uint8_t *s = b.bases.data() + b.offsets[r] + b.start[r];
+    fprintf(f, ">%u:", t);
+    fwrite(b.acc[r].data(), 1, b.acc[r].size(), f);
+    fputc('\n', f);
+    fwrite(s, 1, (size_t)(b.stop[r] - b.start[r] + 1), f);
+    fputc('\n', f);
 }
 
 void ReadSaver::add_batch(const ReadBatch &b, const std::vector<uint32_t> &final_targ)
 {
     for (size_t r = 0; r < b.size(); r++) {
         const uint32_t t = final_targ[r];
-        if (t > 1 && seen_[t] < 12 && f_) { // SAVENUM, :48,:608
-            const uint8_t *s = b.bases.data() + b.offsets[r] + b.start[r];
-            fprintf(f_, ">%u:", t);
-            fwrite(b.acc[r].data(), 1, b.acc[r].size(), f_);
-            fputc('\n', f_);
-            fwrite(s, 1, (size_t)(b.stop[r] - b.start[r] + 1), f_);
-            fputc('\n', f_);
-        }
+        if (t > 1 && seen_[t] < 12 && f_ && first12_enabled_) write_saved(f_, t, b, r); // SAVENUM, :48,:608
+        if (t > 1 && t == save_target_ && f2_) write_saved(f2_, t, b, r);
         seen_[t]++;
     }
 }

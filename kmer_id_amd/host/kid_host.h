@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -63,14 +64,21 @@ struct ReadBatch {
     void clear() { bases.clear(); offsets.assign(1, 0); start.clear(); stop.clear(); acc.clear(); }
 };
 
-// Streams one FASTQ file as batches of trimmed reads.  fill() appends up to max_reads reads that
-// survive process_qual to `out` (which it clears first); returns false when the file is exhausted
-// and nothing was appended.
-class FastqStream {
+// A file of reads delivered as batches.  fill() clears `out`, appends reads until max_reads reads or
+// max_bases bases are in it, and returns false when the file is exhausted and nothing was appended.
+class ReadSource {
+public:
+    virtual ~ReadSource() {}
+    virtual bool fill(ReadBatch &out, size_t max_reads, size_t max_bases) = 0;
+    virtual void close() {}
+};
+
+// process_fqgz (newkmer_10nx.cpp:762-816): FASTQ(.gz), quality-trimmed by process_qual
+class FastqStream : public ReadSource {
 public:
     FastqStream(const std::string &path, int k);
-    bool fill(ReadBatch &out, size_t max_reads);
-    void close() { lines_.close(); }
+    bool fill(ReadBatch &out, size_t max_reads, size_t max_bases = (size_t)-1) override;
+    void close() override { lines_.close(); }
 private:
     GzLines lines_;
     int k_;
@@ -78,18 +86,54 @@ private:
     std::string seq_, acc_;
 };
 
+// process_fagz (newkmer_10nx.cpp:818-875, kmer_read_vf6.cpp:803-861): FASTA(.gz), multi-line records
+// joined, a record is classified whole if it is longer than k
+class FastaGzStream : public ReadSource {
+public:
+    FastaGzStream(const std::string &path, int k);
+    bool fill(ReadBatch &out, size_t max_reads, size_t max_bases = (size_t)-1) override;
+    void close() override { lines_.close(); }
+private:
+    GzLines lines_;
+    int k_;
+    bool eof_ = false;
+    std::string seq_, acc_;
+};
+
+// process_fa / process_fastq (kmer_read_vf6.cpp:863-935; process_fq in kmer_read_m3.cpp): plain
+// text read with getline + `linestream >> token`: only the first whitespace-delimited token of a
+// line counts, and a blank line leaves the previous token in place (it is used again).
+class PlainTokenStream : public ReadSource {
+public:
+    PlainTokenStream(const std::string &path, int k, bool fastq);
+    bool present() const { return open_; }
+    bool fill(ReadBatch &out, size_t max_reads, size_t max_bases = (size_t)-1) override;
+private:
+    struct Impl;
+    std::shared_ptr<Impl> impl_;
+    int k_;
+    bool fastq_, open_, eof_ = false;
+    int mod4_ = 0;
+    std::string lseq_, seq_, acc_;
+};
+
 // ---------------------------------------------------------------- outputs
 // <prefix>_result.txt: "i,gcount[i],ucount[i]\n" for every target (newkmer_10nx.cpp:1040-1043)
 void write_result(const std::string &path, const std::vector<int64_t> &gcount, const std::vector<int64_t> &ucount);
 
-// _reads.txt saver (newkmer_10nx.cpp:608-612): the first 12 reads of every target > 1, file order
+// _reads.txt saver (newkmer_10nx.cpp:608-612): the first 12 reads of every target > 1, file order.
+// kmer_read_vf6 (:612-619) writes that file only when no -target is given, and with -target T all
+// reads of T go to a second file.  An empty path disables the respective file.
 class ReadSaver {
 public:
-    ReadSaver(const std::string &path, int ntar);
+    ReadSaver(const std::string &first12_path, int ntar, const std::string &target_path = "", uint32_t save_target = 0,
+              bool first12_enabled = true);
     ~ReadSaver();
     void add_batch(const ReadBatch &b, const std::vector<uint32_t> &final_targ);
 private:
-    FILE *f_ = nullptr;
+    FILE *f_ = nullptr, *f2_ = nullptr;
+    uint32_t save_target_ = 0;
+    bool first12_enabled_ = true;
     std::vector<int64_t> seen_; // gcount as the reference sees it at that point of the file
 };
 

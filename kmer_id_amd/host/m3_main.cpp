@@ -1,0 +1,138 @@
+// kmer_read_m3 -- command-line compatible replacement of the reference's mitochondria reader, the
+// back end of the Galaxy tool (kmer_read_m3.cpp, main at :973-1131):
+//     kmer_read_m3 -wdir DIR/ -f1 reads1 [-f2 reads2|none]
+// reads DIR/mitochondria_{data.txt,tree.txt,probes.txt.gz}, classifies -f1 and -f2
+// (.fastq.gz / .fasta / .fastq / .fasta.gz) and writes DIR/result.txt.
+// What reaches the kernel: lookups give up after MAXREPROBE = 16 probes (:42,:232), so the table is
+// built sequentially on the host with the reference's exact cell geometry (results depend on it).
+// Extra options: --k K (30) --log2-slots L (30) --device D (0) --batch-reads N
+#include <stdlib.h>
+
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "kid_driver.h"
+
+using namespace kidhost;
+
+static bool ends_with(const std::string &s, const std::string &suffix)
+{
+    return s.size() >= suffix.size() && s.compare(s.size() - suffix.size(), suffix.size(), suffix) == 0;
+}
+
+// suffix order of the reference (:1083-1100): .fastq.gz, .fasta, .fastq, .fasta.gz
+static std::unique_ptr<ReadSource> open_by_suffix(const std::string &name, int k, bool *missing_plain_fasta)
+{
+    if (ends_with(name, ".fastq.gz")) return std::unique_ptr<ReadSource>(new FastqStream(name, k));
+    if (ends_with(name, ".fasta")) {
+        std::unique_ptr<PlainTokenStream> p(new PlainTokenStream(name, k, false));
+        if (!p->present() && missing_plain_fasta) *missing_plain_fasta = true;
+        return std::unique_ptr<ReadSource>(std::move(p));
+    }
+    if (ends_with(name, ".fastq")) return std::unique_ptr<ReadSource>(new PlainTokenStream(name, k, true));
+    if (ends_with(name, ".fasta.gz")) return std::unique_ptr<ReadSource>(new FastaGzStream(name, k));
+    return nullptr;
+}
+
+static long long run_any(Engine &eng, const std::string &name, int k, ReadSaver &saver)
+{
+    bool missing = false;
+    long long n = run_source(eng, [&]() { return open_by_suffix(name, k, &missing); }, saver);
+    if (missing) std::cout << "nark " << name << std::endl;
+    return n;
+}
+
+int main(int argc, char **argv)
+{
+    std::string wdir, r1name, r2name;
+    int k = 30, log2_slots = 30, device = 0;
+    size_t batch_reads = 1 << 20;
+    std::string dry_run; // --dry-run FILE: host stages only (no GPU), for the CPU test-suite
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        const char *v = (i + 1 < argc) ? argv[i + 1] : "";
+        if (a == "-wdir") wdir = v;
+        if (a == "-f1") r1name = v;
+        if (a == "-f2") r2name = v;
+        if (a == "--k") k = atoi(v);
+        if (a == "--log2-slots") log2_slots = atoi(v);
+        if (a == "--device") device = atoi(v);
+        if (a == "--batch-reads") batch_reads = (size_t)atoll(v);
+        if (a == "--dry-run") dry_run = v;
+    }
+    const std::string iname = wdir + "mitochondria_data.txt", tname = wdir + "mitochondria_tree.txt",
+                      pname = wdir + "mitochondria_probes.txt.gz";
+    try {
+        std::cout << "r1 " << r1name << std::endl;
+        std::cout << "r2 " << r2name << std::endl;
+        std::cout << "wd " << wdir << std::endl;
+        int num_targ = 0, num_orgs = 0; // (num_targ is uninitialised in the reference, :981; 0 in practice)
+        {
+            std::ifstream fin(iname);
+            if (!fin) {
+                std::cerr << "kmer_read_m3: cannot read " << iname << "\n";
+                return 3; // the reference builds a zero-sized tree here and crashes later
+            }
+            std::string line, acc;
+            int targi = 0;
+            while (std::getline(fin, line)) {
+                if (!line.empty() && line.back() == '\r') line.pop_back();
+                if (line.length() > 1) {
+                    std::stringstream ls(line);
+                    ls >> targi >> acc;
+                    if (targi > num_targ) num_targ = targi;
+                    num_orgs++;
+                }
+            }
+            std::cout << num_orgs << " strains" << std::endl;
+            num_targ++;
+        }
+        {
+            std::ifstream fin(tname);
+            if (!fin) return 1; // `else exit(1)`, :1060
+        }
+        std::vector<int32_t> parent = load_tree(tname, num_targ);
+        std::cout << "tree loaded" << std::endl;
+        ProbeSet ps = load_probes_gz(pname, k);
+        std::cout << ps.lines_parsed << " kmers loaded" << std::endl;
+        if (ps.lines_parsed < 2) return 1; // :1067
+
+        if (!dry_run.empty()) {
+            FILE *f = fopen(dry_run.c_str(), "w");
+            if (!f) { perror("kmer_read_m3"); return 2; }
+            dry_dump_db(f, parent, ps);
+            for (const std::string &name : {r1name, r2name}) {
+                if (name.empty() || name == "none") continue;
+                std::unique_ptr<ReadSource> src = open_by_suffix(name, k, nullptr);
+                if (src) dry_dump_source(f, name, *src, batch_reads);
+            }
+            fclose(f);
+            return 0;
+        }
+        Engine eng;
+        eng.batch_reads = batch_reads;
+        if (!engine_open(eng, ps, parent, k, log2_slots, /*MAXREPROBE*/ 16, 0, device)) {
+            std::cout << "out of memory in table " << std::endl;
+            return 1;
+        }
+        ps = ProbeSet();
+
+        if (r1name.empty()) throw Fatal{134, "no -f1 given (std::out_of_range in the reference, :1080)"};
+        std::cout << r1name.length() << " : " << r1name[r1name.length() - 1] << std::endl;
+        ReadSaver saver("", num_targ); // the reads file is commented out in this program (:612-621)
+        long long tct = run_any(eng, r1name, k, saver);
+        std::cout << tct << " reads loaded" << std::endl;
+        if (r2name.length() > 1 && r2name != "none") {
+            const bool fqgz = ends_with(r2name, ".fastq.gz");
+            tct += run_any(eng, r2name, k, saver);
+            if (fqgz) std::cout << tct << " reads loaded" << std::endl; // printed inside that branch too (:1107)
+            std::cout << tct << " reads loaded" << std::endl;
+        }
+        finish_sample(eng, wdir + "result.txt");
+    } catch (const Fatal &f) {
+        std::cerr << f.message << "\n";
+        return f.exit_code;
+    }
+    return 0;
+}

@@ -23,81 +23,9 @@
 #include <mutex>
 #include <thread>
 
-#include "kid_host.h"
-#include "kmer_id_amd.h"
+#include "kid_driver.h"
 
 using namespace kidhost;
-
-static void die_kid(int rc)
-{
-    std::cerr << "nk10: " << kid_strerror(rc) << ": " << kid_last_error() << "\n";
-    exit(rc == KID_ERR_TABLE_FULL ? 1 : 3);
-}
-
-namespace {
-struct Pipe { // bounded hand-off of parsed batches from the reader thread to the GPU thread
-    std::mutex m;
-    std::condition_variable cv;
-    std::deque<std::unique_ptr<ReadBatch>> q;
-    bool done = false;
-    bool failed = false;
-    Fatal failure{0, ""};
-};
-}
-
-// one FASTQ file: parse + trim on a reader thread, classify batch by batch on the caller's thread
-static long long run_file(const std::string &path, int k, size_t batch_reads, kid_sample *sample, ReadSaver &saver)
-{
-    Pipe pipe;
-    std::thread reader([&]() {
-        try {
-            FastqStream fq(path, k);
-            for (;;) {
-                std::unique_ptr<ReadBatch> b(new ReadBatch());
-                bool more = fq.fill(*b, batch_reads);
-                if (!more) break;
-                std::unique_lock<std::mutex> lk(pipe.m);
-                pipe.cv.wait(lk, [&] { return pipe.q.size() < 3; });
-                pipe.q.push_back(std::move(b));
-                pipe.cv.notify_all();
-            }
-            fq.close();
-        } catch (const Fatal &f) {
-            std::lock_guard<std::mutex> lk(pipe.m);
-            pipe.failed = true;
-            pipe.failure = f;
-        }
-        std::lock_guard<std::mutex> lk(pipe.m);
-        pipe.done = true;
-        pipe.cv.notify_all();
-    });
-    long long n = 0;
-    std::vector<uint32_t> final_targ;
-    int rc = KID_OK;
-    for (;;) {
-        std::unique_ptr<ReadBatch> b;
-        {
-            std::unique_lock<std::mutex> lk(pipe.m);
-            pipe.cv.wait(lk, [&] { return !pipe.q.empty() || pipe.done; });
-            if (pipe.q.empty()) break;
-            b = std::move(pipe.q.front());
-            pipe.q.pop_front();
-            pipe.cv.notify_all();
-        }
-        if (rc != KID_OK) continue; // drain
-        final_targ.resize(b->size());
-        rc = kid_classify_batch(sample, b->bases.data(), b->offsets.data(), b->start.data(), b->stop.data(), b->size(),
-                                final_targ.data());
-        if (rc == KID_OK) {
-            saver.add_batch(*b, final_targ);
-            n += (long long)b->size();
-        }
-    }
-    reader.join();
-    if (rc != KID_OK) die_kid(rc);
-    if (pipe.failed) throw pipe.failure; // reads parsed before the failure were processed, as in the reference
-    return n;
-}
 
 int main(int argc, char **argv)
 {
@@ -152,10 +80,7 @@ int main(int argc, char **argv)
         if (!dry_run.empty()) { // host stages only
             FILE *f = fopen(dry_run.c_str(), "w");
             if (!f) { perror("nk10"); return 2; }
-            fprintf(f, "PARENT %d\n", ntar);
-            for (int i = 0; i < ntar; i++) if (parent[(size_t)i] != 1) fprintf(f, "%d %d\n", i, parent[(size_t)i]);
-            fprintf(f, "PROBES %zu %lld\n", ps.keys.size(), ps.lines_parsed);
-            for (size_t i = 0; i < ps.keys.size(); i++) fprintf(f, "%llu %u\n", (unsigned long long)ps.keys[i], ps.targets[i]);
+            dry_dump_db(f, parent, ps);
             DIR *dd = opendir(dname.c_str());
             std::vector<std::string> names;
             if (dd) {
@@ -169,22 +94,18 @@ int main(int argc, char **argv)
             for (const std::string &prefix : names)
                 for (const std::string &suffix : {e1, e2}) {
                     FastqStream fq(dname + prefix + suffix, k);
-                    ReadBatch b;
-                    fprintf(f, "FILE %s%s\n", prefix.c_str(), suffix.c_str());
-                    while (fq.fill(b, batch_reads))
-                        for (size_t r = 0; r < b.size(); r++)
-                            fprintf(f, "%s\t%d\t%d\t%llu\n", b.acc[r].c_str(), b.start[r], b.stop[r],
-                                    (unsigned long long)(b.offsets[r + 1] - b.offsets[r]));
-                    fq.close();
+                    dry_dump_source(f, prefix + suffix, fq, batch_reads);
                 }
             fclose(f);
             return 0;
         }
 
-        kid_db *db = nullptr;
-        int rc = kid_db_build(ps.keys.data(), ps.targets.data(), ps.keys.size(), parent.data(), ntar, k, log2_slots, 0, 0, device, &db);
-        if (rc == KID_ERR_TABLE_FULL) { std::cout << "out of memory in table " << std::endl; return 1; } // :256-260
-        if (rc != KID_OK) die_kid(rc);
+        Engine eng;
+        eng.batch_reads = batch_reads;
+        if (!engine_open(eng, ps, parent, k, log2_slots, 0, 0, device)) { // :256-260
+            std::cout << "out of memory in table " << std::endl;
+            return 1;
+        }
         ps = ProbeSet();
 
         // ---- find the samples (:992-1014): every directory entry whose name contains the R1 suffix
@@ -203,28 +124,21 @@ int main(int argc, char **argv)
         }
         closedir(dir);
 
-        kid_sample *sample = nullptr;
-        rc = kid_sample_begin(db, &sample);
-        if (rc != KID_OK) die_kid(rc);
-        std::vector<int64_t> gcount((size_t)ntar), ucount((size_t)ntar);
         for (const std::string &prefix : fnames) { // :1015-1045
-            rc = kid_sample_reset(sample);
+            int rc = kid_sample_reset(eng.sample);
             if (rc != KID_OK) die_kid(rc);
             std::cout << prefix << std::endl;
             long long tct = 0;
             {
                 ReadSaver saver(dname + prefix + "_reads.txt", ntar);
-                tct += run_file(dname + prefix + e1, k, batch_reads, sample, saver);
-                std::cout << tct << " reads loaded" << std::endl;
-                tct += run_file(dname + prefix + e2, k, batch_reads, sample, saver);
-                std::cout << tct << " reads loaded" << std::endl;
+                for (const std::string &suffix : {e1, e2}) {
+                    const std::string path = dname + prefix + suffix;
+                    tct += run_source(eng, [&]() { return std::unique_ptr<ReadSource>(new FastqStream(path, k)); }, saver);
+                    std::cout << tct << " reads loaded" << std::endl;
+                }
             }
-            rc = kid_sample_end(sample, gcount.data(), ucount.data());
-            if (rc != KID_OK) die_kid(rc);
-            write_result(dname + prefix + "_result.txt", gcount, ucount);
+            finish_sample(eng, dname + prefix + "_result.txt");
         }
-        kid_sample_destroy(sample);
-        kid_db_destroy(db);
     } catch (const Fatal &f) {
         std::cerr << f.message << "\n";
         return f.exit_code;

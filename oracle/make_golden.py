@@ -324,9 +324,153 @@ def make_e2e_seeded():
     print("e2e_seeded: result %d bytes, reads %d bytes" % (len(res), len(rds)))
 
 
+def _mixed_records(rng, keys, n, with_u=True):
+    """(acc, seq, qual) records with DB k-mers, lower case, N and (optionally) U bases"""
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(25, 320))
+        s = list("".join(rng.choice(list("ACGT"), L)))
+        for _ in range(int(rng.integers(0, 4))):
+            if L >= 30:
+                p = int(rng.integers(0, L - 29))
+                ks = synth.key_to_seq(int(keys[rng.integers(0, keys.size)]))
+                if rng.random() < 0.5:
+                    ks = revcomp_seq(ks)
+                s[p:p + 30] = list(ks)
+        s = "".join(s)
+        r = rng.random()
+        if with_u and r < 0.3:
+            s = s.replace("T", "U", int(rng.integers(1, 6)))
+        elif r < 0.4:
+            s = s.lower()
+        elif r < 0.5:
+            p = int(rng.integers(0, L)); s = s[:p] + "N" + s[p + 1:]
+        q = "".join(chr(int(c)) for c in np.where(np.arange(L) >= L - int(rng.integers(0, 15)), 36, 72))
+        recs.append(("r%d" % i, s, q))
+    return recs
+
+
+def _write_inputs(d, rng, keys, with_u):
+    """four files, one per reader: .fastq.gz, .fasta.gz (multi-line), .fasta and .fastq (plain, with the
+    token/blank-line quirks of the getline + >> readers)"""
+    recs = _mixed_records(rng, keys, 400, with_u)
+    with gzip.open(os.path.join(d, "a.fastq.gz"), "wb") as fh:
+        fh.write("".join("@%s\n%s\n+\n%s\n" % r for r in recs[:120]).encode())
+    with gzip.open(os.path.join(d, "b.fasta.gz"), "wb") as fh:
+        out = []
+        for acc, s, _ in recs[120:220]:
+            out.append(">%s some description" % acc)
+            for i in range(0, len(s), 70):
+                out.append(s[i:i + 70])
+        long = "".join(r[1] for r in recs[220:240]).replace("N", "A")
+        out.append(">contig_long")
+        out += [long[i:i + 60] for i in range(0, len(long), 60)]
+        fh.write(("\n".join(out) + "\n").encode())
+    with open(os.path.join(d, "c.fasta"), "w", newline="") as fh:
+        out = []
+        for j, (acc, s, _) in enumerate(recs[240:320]):
+            out.append(">%s extra tokens ignored" % acc)
+            out.append(s[:len(s) // 2] + "   trailing junk")
+            if j % 7 == 3:
+                out.append("")            # blank line: the previous token is appended again
+            out.append(s[len(s) // 2:])
+            if j % 11 == 5:
+                out.append("   ")
+        fh.write("\r\n".join(out) + "\r\n")
+    with open(os.path.join(d, "d.fastq"), "w", newline="") as fh:
+        out = []
+        for j, (acc, s, q) in enumerate(recs[320:400]):
+            # (a blank line here would re-use the previous token, shift the 4-line phase and make the
+            #  reference die in qual.at(): covered by the exit-code test instead)
+            out += ["@%s comment" % acc, s + "\tjunk", "+", q + " junk"]
+        fh.write("\n".join(out) + "\n")
+    return ["a.fastq.gz", "b.fasta.gz", "c.fasta", "d.fastq"]
+
+
+def make_e2e_vf6():
+    rng = np.random.default_rng(11)
+    parent, cnt = synth.load_taxonomy("bact10")
+    cum = synth.cumulative(synth.scaled_counts(cnt, E2E_SCALE))
+    keys, targets = synth.db_keys(cum, K)
+    cwd = tempfile.mkdtemp(prefix="vf6_")
+    os.makedirs(os.path.join(cwd, "DB")); os.makedirs(os.path.join(cwd, "J"))
+    write_tree(os.path.join(cwd, "DB", "DB_tree.txt"), parent, crlf=True)
+    with open(os.path.join(cwd, "DB", "DB_data.txt"), "w", newline="") as fh:
+        for t in range(2, parent.size, 37):
+            fh.write("%d\tACC%06d\r\n" % (t, t))
+        fh.write("%d\tLAST\r\n" % (parent.size - 1))
+    synth.write_probes_gz(os.path.join(cwd, "DB", "DB_probes.txt.gz"), keys, targets, K)
+    ind = os.path.join(cwd, "in"); os.makedirs(ind)
+    files = _write_inputs(ind, rng, keys, with_u=True)
+    with open(os.path.join(cwd, "J", "J.txt"), "w") as fh:
+        fh.write("jobA 2\nin/%s\nin/%s\n\njobB 2\nin/%s\nin/%s\n" % tuple(files))
+    hot = int(targets[len(targets) // 3])
+    outdir = os.path.join(GOLD, "e2e_vf6")
+    shutil.rmtree(outdir, ignore_errors=True)
+    os.makedirs(os.path.join(outdir, "in"))
+    for f in files:
+        shutil.copy(os.path.join(ind, f), os.path.join(outdir, "in", f))
+    shutil.copy(os.path.join(cwd, "J", "J.txt"), os.path.join(outdir, "J.txt"))
+    shutil.copy(os.path.join(cwd, "DB", "DB_data.txt"), os.path.join(outdir, "DB_data.txt"))
+    for tag, extra in (("plain", []), ("target", ["-target", str(hot)])):
+        out = subprocess.run([os.path.join(REF, "vf6_ref_small"), "-name", "DB", "-jname", "J"] + extra, cwd=cwd,
+                             stdout=subprocess.PIPE, check=True).stdout.decode()
+        os.makedirs(os.path.join(outdir, tag))
+        with open(os.path.join(outdir, tag, "stdout.txt"), "w") as fh:
+            fh.write(out)
+        for f in sorted(os.listdir(os.path.join(cwd, "J"))):
+            if f != "J.txt":
+                shutil.move(os.path.join(cwd, "J", f), os.path.join(outdir, tag, f))
+    with open(os.path.join(outdir, "params.json"), "w") as fh:
+        json.dump({"db": "bact10", "scale": E2E_SCALE, "k": K, "target": hot, "log2_slots": 22}, fh)
+    shutil.rmtree(cwd)
+    print("e2e_vf6:", sorted(os.listdir(os.path.join(outdir, "plain"))), sorted(os.listdir(os.path.join(outdir, "target"))))
+
+
+def make_e2e_m3():
+    """kmer_read_m3 with its 16-probe cap on a table that is ~87 % full (m3_ref_tiny: 2^16 cells)"""
+    rng = np.random.default_rng(12)
+    parent, cnt = synth.load_taxonomy("mito")
+    c = synth.scaled_counts(cnt, 2.7e-3)
+    cum = synth.cumulative(c)
+    keys, targets = synth.db_keys(cum, K, seed=0x317)
+    assert 0.8 < keys.size / 65536 < 0.95, keys.size
+    cwd = tempfile.mkdtemp(prefix="m3_")
+    wd = os.path.join(cwd, "wd") + "/"
+    os.makedirs(wd)
+    write_tree(wd + "mitochondria_tree.txt", parent)
+    with open(wd + "mitochondria_data.txt", "w") as fh:
+        for t in range(2, parent.size, 53):
+            fh.write("%d\tNC_%06d\n" % (t, t))
+        fh.write("%d\tNC_LAST\n" % (parent.size - 1))
+    synth.write_probes_gz(wd + "mitochondria_probes.txt.gz", keys, targets, K)
+    files = _write_inputs(wd, rng, keys, with_u=False)
+    outdir = os.path.join(GOLD, "e2e_m3")
+    shutil.rmtree(outdir, ignore_errors=True)
+    os.makedirs(outdir)
+    for f in files:
+        shutil.copy(wd + f, os.path.join(outdir, f))
+    shutil.copy(wd + "mitochondria_data.txt", os.path.join(outdir, "mitochondria_data.txt"))
+    runs = {"fqgz_fagz": ("a.fastq.gz", "b.fasta.gz"), "fa_fq": ("c.fasta", "d.fastq"), "single": ("a.fastq.gz", "none")}
+    for tag, (f1, f2) in runs.items():
+        out = subprocess.run([os.path.join(REF, "m3_ref_tiny"), "-wdir", wd, "-f1", wd + f1, "-f2", (wd + f2) if f2 != "none" else "none"],
+                             cwd=cwd, stdout=subprocess.PIPE, check=True).stdout.decode()
+        with open(os.path.join(outdir, tag + "_stdout.txt"), "w") as fh:
+            fh.write(out.replace(wd, "<WD>"))
+        shutil.move(wd + "result.txt", os.path.join(outdir, tag + "_result.txt"))
+    with open(os.path.join(outdir, "params.json"), "w") as fh:
+        json.dump({"db": "mito", "scale": 2.7e-3, "k": K, "db_seed": 0x317, "log2_slots": 16, "n_keys": int(keys.size), "runs": runs}, fh)
+    shutil.rmtree(cwd)
+    print("e2e_m3:", sorted(os.listdir(outdir)))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["kat", "small", "seeded"]
+    what = sys.argv[1:] or ["kat", "small", "seeded", "vf6", "m3"]
+    if "vf6" in what:
+        make_e2e_vf6()
+    if "m3" in what:
+        make_e2e_m3()
     if "kat" in what:
         make_kat()
     if "small" in what:

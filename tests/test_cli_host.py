@@ -61,8 +61,8 @@ def parse_dry(path):
         elif sec == "probes":
             a, b = line.split(); probes.append((int(a), int(b)))
         else:
-            acc, st, sp, ln = line.rsplit("\t", 3)
-            files[sec].append((acc, int(st), int(sp), int(ln)))
+            acc, st, sp, seq = line.split("\t")
+            files[sec].append((acc, int(st), int(sp), len(seq)))
     return hdr, parent, probes, files
 
 
