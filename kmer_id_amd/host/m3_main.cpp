@@ -38,6 +38,7 @@ static std::unique_ptr<ReadSource> open_by_suffix(const std::string &name, int k
 static long long run_any(Engine &eng, const std::string &name, int k, ReadSaver &saver)
 {
     bool missing = false;
+    if (ends_with(name, ".fasta.gz") && !ends_with(name, ".fastq.gz")) std::cout << "true" << std::endl; // process_fagz, :789
     long long n = run_source(eng, [&]() { return open_by_suffix(name, k, &missing); }, saver);
     if (missing) std::cout << "nark " << name << std::endl;
     return n;
