@@ -16,6 +16,20 @@ void die_kid(int rc)
     exit(rc == KID_ERR_TABLE_FULL ? 1 : 3);
 }
 
+void load_database(const std::string &tree_path, const std::string &probes_path, const std::string &cache_path, int k, int ntar,
+                   std::vector<int32_t> &parent, ProbeSet &ps, bool *from_cache)
+{
+    if (from_cache) *from_cache = false;
+    if (!cache_path.empty() && load_db_cache(cache_path, tree_path, probes_path, k, ntar, parent, ps)) {
+        if (from_cache) *from_cache = true;
+        return;
+    }
+    parent = load_tree(tree_path, ntar);
+    ps = load_probes_gz(probes_path, k);
+    if (!cache_path.empty() && !save_db_cache(cache_path, tree_path, probes_path, k, parent, ps))
+        std::cerr << "kmer_id_amd: could not write the database cache " << cache_path << "\n";
+}
+
 Engine::~Engine()
 {
     if (sample) kid_sample_destroy(sample);

@@ -22,6 +22,11 @@ struct Engine {
 
 [[noreturn]] void die_kid(int rc);
 
+// tree + probes, from the binary cache when `cache_path` names a valid one, else from the text files
+// (and the cache is written for the next run).  `from_cache` reports which way it went.
+void load_database(const std::string &tree_path, const std::string &probes_path, const std::string &cache_path, int k, int ntar,
+                   std::vector<int32_t> &parent, ProbeSet &ps, bool *from_cache = nullptr);
+
 // Hashtable + Tree1 onto the GPU.  Returns false where the reference prints "out of memory in table"
 // and exits with 1 (newkmer_10nx.cpp:256-260).
 bool engine_open(Engine &e, const ProbeSet &ps, const std::vector<int32_t> &parent, int k, int log2_slots, int max_probes,

@@ -3,6 +3,7 @@
 #include "kid_host.h"
 
 #include <string.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <fstream>
@@ -185,6 +186,74 @@ ProbeSet load_probes_gz(const std::string &path, int k)
     }
     in.close();
     return ps;
+}
+
+// ---------------------------------------------------------------- binary database cache
+namespace {
+struct CacheHeader {
+    char magic[8];
+    int32_t k, ntar;
+    uint64_t n_entries;
+    int64_t lines_parsed;
+    uint64_t stamp[4]; // tree size, tree mtime (ns), probes size, probes mtime (ns); 0 for a missing file
+};
+
+void file_stamp(const std::string &path, uint64_t &size, uint64_t &mtime_ns)
+{
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) { size = 0; mtime_ns = 0; return; }
+    size = (uint64_t)st.st_size;
+    mtime_ns = (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec;
+}
+}
+
+bool load_db_cache(const std::string &cache_path, const std::string &tree_path, const std::string &probes_path, int k, int ntar,
+                   std::vector<int32_t> &parent, ProbeSet &ps)
+{
+    FILE *f = fopen(cache_path.c_str(), "rb");
+    if (!f) return false;
+    CacheHeader h;
+    uint64_t stamp[4];
+    file_stamp(tree_path, stamp[0], stamp[1]);
+    file_stamp(probes_path, stamp[2], stamp[3]);
+    bool ok = fread(&h, sizeof(h), 1, f) == 1 && memcmp(h.magic, "KIDX0001", 8) == 0 && h.k == k && h.ntar == ntar &&
+              memcmp(h.stamp, stamp, sizeof(stamp)) == 0 && stamp[2] != 0;
+    if (ok) {
+        parent.resize((size_t)ntar);
+        ps.keys.resize(h.n_entries);
+        ps.targets.resize(h.n_entries);
+        ps.lines_parsed = h.lines_parsed;
+        ok = fread(parent.data(), sizeof(int32_t), (size_t)ntar, f) == (size_t)ntar &&
+             fread(ps.keys.data(), sizeof(uint64_t), h.n_entries, f) == h.n_entries &&
+             fread(ps.targets.data(), sizeof(uint32_t), h.n_entries, f) == h.n_entries;
+    }
+    fclose(f);
+    if (!ok) { ps = ProbeSet(); parent.clear(); }
+    return ok;
+}
+
+bool save_db_cache(const std::string &cache_path, const std::string &tree_path, const std::string &probes_path, int k,
+                   const std::vector<int32_t> &parent, const ProbeSet &ps)
+{
+    const std::string tmp = cache_path + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    CacheHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "KIDX0001", 8);
+    h.k = k;
+    h.ntar = (int32_t)parent.size();
+    h.n_entries = ps.keys.size();
+    h.lines_parsed = ps.lines_parsed;
+    file_stamp(tree_path, h.stamp[0], h.stamp[1]);
+    file_stamp(probes_path, h.stamp[2], h.stamp[3]);
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(parent.data(), sizeof(int32_t), parent.size(), f) == parent.size() &&
+              fwrite(ps.keys.data(), sizeof(uint64_t), ps.keys.size(), f) == ps.keys.size() &&
+              fwrite(ps.targets.data(), sizeof(uint32_t), ps.targets.size(), f) == ps.targets.size();
+    ok = (fclose(f) == 0) && ok;
+    if (ok) ok = rename(tmp.c_str(), cache_path.c_str()) == 0;
+    if (!ok) remove(tmp.c_str());
+    return ok;
 }
 
 // ---------------------------------------------------------------- trimming

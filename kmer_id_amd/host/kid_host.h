@@ -33,6 +33,15 @@ struct ProbeSet {
 // process_kmergz (newkmer_10nx.cpp:663-712).  Throws Fatal{255} on gz errors / over-long lines.
 ProbeSet load_probes_gz(const std::string &path, int k);
 
+// Binary cache of the parsed database: what load_tree + load_probes_gz produce, so that a
+// later run skips the text parse (minutes for 108 M lines).  The cache is tied to the size and
+// modification time of the two text files and to k / ntar; anything else makes it stale.
+//   layout: "KIDX0001", k, ntar, n_entries, lines_parsed, 4 file stamps, parent[ntar], keys[n], targets[n]
+bool load_db_cache(const std::string &cache_path, const std::string &tree_path, const std::string &probes_path, int k, int ntar,
+                   std::vector<int32_t> &parent, ProbeSet &ps);
+bool save_db_cache(const std::string &cache_path, const std::string &tree_path, const std::string &probes_path, int k,
+                   const std::vector<int32_t> &parent, const ProbeSet &ps);
+
 // ---------------------------------------------------------------- reads
 // process_qual (newkmer_10nx.cpp:714-760).  returns true when process_read would be called.
 // Throws Fatal{134} where qual.at() would throw (quality shorter than sequence).

@@ -50,6 +50,7 @@ int main(int argc, char **argv)
     int k = 30, log2_slots = 30, device = 0;
     size_t batch_reads = 1 << 20;
     std::string dry_run; // --dry-run FILE: host stages only (no GPU), for the CPU test-suite
+    std::string db_cache; // --db-cache FILE: binary cache of the parsed database
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         const char *v = (i + 1 < argc) ? argv[i + 1] : "";
@@ -61,6 +62,7 @@ int main(int argc, char **argv)
         if (a == "--device") device = atoi(v);
         if (a == "--batch-reads") batch_reads = (size_t)atoll(v);
         if (a == "--dry-run") dry_run = v;
+        if (a == "--db-cache") db_cache = v;
     }
     const std::string iname = wdir + "mitochondria_data.txt", tname = wdir + "mitochondria_tree.txt",
                       pname = wdir + "mitochondria_probes.txt.gz";
@@ -93,9 +95,10 @@ int main(int argc, char **argv)
             std::ifstream fin(tname);
             if (!fin) return 1; // `else exit(1)`, :1060
         }
-        std::vector<int32_t> parent = load_tree(tname, num_targ);
+        std::vector<int32_t> parent;
+        ProbeSet ps;
+        load_database(tname, pname, db_cache, k, num_targ, parent, ps);
         std::cout << "tree loaded" << std::endl;
-        ProbeSet ps = load_probes_gz(pname, k);
         std::cout << ps.lines_parsed << " kmers loaded" << std::endl;
         if (ps.lines_parsed < 2) return 1; // :1067
 

@@ -9,6 +9,7 @@
 // Options after the directory (all optional, defaults = the reference's compile-time constants):
 //   --db-dir DIR (./bact10/)  --ntar N (5982)  --k K (30)  --log2-slots L (30)  --device D (0)
 //   --batch-reads N (1048576)  --r1 SUFFIX (_R1_tr.fastq.gz)  --r2 SUFFIX (_R2_tr.fastq.gz)
+//   --db-cache FILE  binary cache of the parsed database: read if valid, (re)written otherwise
 //   --dry-run FILE   host stages only (no GPU): parse the DB text files and the FASTQ files,
 //                    write what WOULD be handed to the GPU to FILE (used by the CPU test-suite)
 #include <dirent.h>
@@ -32,7 +33,7 @@ int main(int argc, char **argv)
     std::string dname, db_dir = "./bact10/", e1 = "_R1_tr.fastq.gz", e2 = "_R2_tr.fastq.gz";
     int ntar = 5982, k = 30, log2_slots = 30, device = 0;
     size_t batch_reads = 1 << 20;
-    std::string dry_run;
+    std::string dry_run, db_cache;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&](const char *name) -> const char * {
@@ -48,6 +49,7 @@ int main(int argc, char **argv)
         else if (a == "--r1") e1 = val("--r1");
         else if (a == "--r2") e2 = val("--r2");
         else if (a == "--dry-run") dry_run = val("--dry-run");
+        else if (a == "--db-cache") db_cache = val("--db-cache");
         else if (dname.empty()) dname = a;
         else { std::cerr << "nk10: unexpected argument " << a << "\n"; return 2; }
     }
@@ -72,9 +74,10 @@ int main(int argc, char **argv)
                 if (g) { fclose(g); tpath = alt; }
             }
         }
-        std::vector<int32_t> parent = load_tree(tpath, ntar);
+        std::vector<int32_t> parent;
+        ProbeSet ps;
+        load_database(tpath, pname, db_cache, k, ntar, parent, ps);
         std::cout << "tree loaded" << std::endl;
-        ProbeSet ps = load_probes_gz(pname, k);
         std::cout << ps.lines_parsed << " kmers loaded" << std::endl;
 
         if (!dry_run.empty()) { // host stages only

@@ -43,6 +43,7 @@ int main(int argc, char **argv)
     int save_target = 0, k = 30, log2_slots = 30, device = 0;
     size_t batch_reads = 1 << 20;
     std::string dry_run; // --dry-run FILE: host stages only (no GPU), for the CPU test-suite
+    std::string db_cache; // --db-cache FILE: binary cache of the parsed database
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         const char *v = (i + 1 < argc) ? argv[i + 1] : "";
@@ -55,6 +56,7 @@ int main(int argc, char **argv)
         if (a == "--device") device = atoi(v);
         if (a == "--batch-reads") batch_reads = (size_t)atoll(v);
         if (a == "--dry-run") dry_run = v;
+        if (a == "--db-cache") db_cache = v;
     }
     const std::string iname = wdir + dname + "_data.txt", tname = wdir + dname + "_tree.txt",
                       pname = wdir + dname + "_probes.txt.gz", jfile = jdir + jname + ".txt";
@@ -116,9 +118,10 @@ int main(int argc, char **argv)
             std::cout << num_targ << " targs" << std::endl;
             num_targ++;
         }
-        std::vector<int32_t> parent = load_tree(tname, num_targ);
+        std::vector<int32_t> parent;
+        ProbeSet ps;
+        load_database(tname, pname, db_cache, k, num_targ, parent, ps);
         std::cout << "tree loaded" << std::endl;
-        ProbeSet ps = load_probes_gz(pname, k);
         std::cout << ps.lines_parsed << " kmers loaded" << std::endl;
 
         if (!dry_run.empty()) {

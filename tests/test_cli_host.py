@@ -183,3 +183,31 @@ def test_nk10_unreadable_directory(nk10, tmp_path):
     make_db_dir(cwd, 2e-5)
     r = subprocess.run([nk10, os.path.join(cwd, "nope") + "/", "--log2-slots", "16"], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and b"hosed" in r.stdout
+
+
+def test_db_cache_round_trip(nk10, tmp_path):
+    """--db-cache: the second run loads the binary cache and hands over exactly the same database;
+    touching the probes file makes the cache stale"""
+    cwd = str(tmp_path)
+    parent, cum, keys, targets = make_db_dir(cwd, 2e-4)
+    fq = os.path.join(cwd, "fq"); os.makedirs(fq)
+    with gzip.open(os.path.join(fq, "S_R1_tr.fastq.gz"), "wb") as fh:
+        fh.write(b"@a\nACGT\n+\nIIII\n")
+    with gzip.open(os.path.join(fq, "S_R2_tr.fastq.gz"), "wb") as fh:
+        fh.write(b"@b\nACGT\n+\nIIII\n")
+    cache = os.path.join(cwd, "db.kidx")
+    def run(tag):
+        dump = os.path.join(cwd, tag + ".txt")
+        r = subprocess.run([nk10, fq + "/", "--dry-run", dump, "--db-cache", cache], cwd=cwd, check=True, stdout=subprocess.PIPE)
+        return open(dump, "rb").read(), r.stdout
+    first, out1 = run("first")
+    assert os.path.getsize(cache) == 8 + 8 + 8 + 8 + 32 + 4 * 5982 + 12 * keys.size
+    mtime = os.path.getmtime(cache)
+    second, out2 = run("second")
+    assert first == second and out1 == out2
+    assert os.path.getmtime(cache) == mtime                    # served from the cache, not rewritten
+    # a different probes file -> stale -> re-parsed and rewritten
+    synth.write_probes_gz(os.path.join(cwd, "bact10", "probes10.txt.gz"), keys[:1000], targets[:1000], K)
+    third, _ = run("third")
+    assert third != first and b"PROBES 1000 1000" in third
+    assert os.path.getsize(cache) == 64 + 4 * 5982 + 12 * 1000

@@ -523,3 +523,30 @@ def test_merge_sample_over_rccl_single_rank(seeded):
             dist.destroy_process_group()
     assert np.array_equal(gm, g) and np.array_equal(um, u)
     s.close()
+
+
+def test_config5_fungal_vf6_250bp():
+    """BASELINE configs[4]: fungal taxonomy (derived from the reference's fung1_list_vf6.txt by
+    tools/taxonomy_from_list.py, 7078 nodes, 7 ranks deep), synthetic probes, 250 bp reads, U = T"""
+    parent, cnt = synth.load_taxonomy("fungal")
+    cum = synth.cumulative(synth.scaled_counts(cnt, 0.02))
+    keys, targets = synth.db_keys(cum, K, seed=0xF6)
+    odb = oracle_db(parent, keys, targets, 19, flags=ob.KO_FLAG_U_IS_T)
+    n, L = 12000, 250
+    bases = synth.reads(cum, parent, n, L, K, db_seed=0xF6, read_seed=0x250).copy()
+    t = np.flatnonzero(bases == ord("T"))
+    bases[t[::5]] = ord("U")
+    off = synth.fixed_offsets(n, L)
+    os_ = ob.OracleSample(odb)
+    exp = os_.classify(bases, off)
+    eg, eu = os_.counts()
+    assert (exp > 1).sum() > n // 4 and len(np.unique(exp)) > 500
+    for flags in (KID_FLAG_U_IS_T, KID_FLAG_U_IS_T | KID_FLAG_REF_GEOMETRY):
+        db = KmerDB(keys, targets, parent, k=K, log2_slots=19, flags=flags)
+        assert db.info.tree_depth == 7 and db.info.ntar == 7078
+        s = db.sample()
+        assert np.array_equal(s.classify(bases, off), exp)
+        g, u = s.end()
+        assert np.array_equal(g, eg) and np.array_equal(u, eu)
+        assert s.stats()["lookups"] == os_.stats()["lookups"]
+        s.close(); db.close()
