@@ -370,6 +370,7 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
             const uint32_t nchunks = (sh + nb + 15u) >> 4; // <= 64
 
             // ---- 1. stage the packed segment
+            bool seg_clean;
             {
                 uint32_t codes = st_codes, inv = st_inv;
                 if (seg != 0) { // long reads: later segments are fetched on the spot
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
                 W[lane] = codes;
                 IM16[lane] = (uint16_t)inv;
                 if (lane < 2) { W[64 + lane] = 0; IM[32 + lane] = 0; }
+                seg_clean = (__ballot(inv != 0) == 0); // wave-uniform: no base of this segment resets a window
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -392,36 +394,43 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
                 uint64_t key[U];
                 uint32_t hlo[U]; // reference geometry: first cell of the probe sequence; minloc: the minimizer
                 bool act[U];
+                uint32_t P[U + 1], S[U]; // minloc: row prefix / suffix minima of the hashed m-mers
+                const uint32_t pmax = sh + nb - (uint32_t)mlen; // last m-mer start inside the segment
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const uint32_t i = t0 + (uint32_t)u * 64u + lane;
-                    const uint32_t p = sh + (i < segk ? i : 0u);
+                    // one window extraction serves the k-mer AND the m-mer that starts at the same base;
+                    // lanes past the last k-mer still hash their m-mer (the windows of earlier lanes reach
+                    // 14 positions ahead), clamped to the last one that lies inside the segment
+                    uint32_t p = sh + i;
+                    p = MINLOC ? (p < pmax ? p : pmax) : sh + (i < segk ? i : 0u);
                     const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
                     const uint64_t A = ((uint64_t)W[w0] << 32) | W[w0 + 1];
                     const uint64_t B = W[w0 + 2];
                     const uint64_t x = (A << o2) | ((B << o2) >> 32);
                     const uint64_t keyF = x >> (64 - 2 * k);
-                    const uint64_t im = (((uint64_t)IM[(p >> 5) + 1] << 32) | IM[p >> 5]) >> (p & 31u);
-                    const bool valid = (i < segk) && ((im & ((1ull << k) - 1ull)) == 0);
+                    bool valid = (i < segk);
+                    if (!seg_clean) { // rare: some base of the segment is not ACGTacgt
+                        const uint64_t im = (((uint64_t)IM[(p >> 5) + 1] << 32) | IM[p >> 5]) >> (p & 31u);
+                        valid = valid && ((im & ((1ull << k) - 1ull)) == 0);
+                    }
                     key[u] = kid_canonical(keyF, k);
                     if (!MINLOC) hlo[u] = (uint32_t)kid_fmix64(key[u]) & db.slot_mask;
                     act[u] = valid;
                     n_lookups += valid ? 1u : 0u;
+                    if (MINLOC) {
+                        const uint32_t h = kid_mmer_hash((uint32_t)(x >> (64 - 2 * mlen)), mlen);
+                        P[u] = kid_row_prefix_min(h);
+                        S[u] = kid_row_suffix_min(h);
+                    }
                 }
                 if (MINLOC) {
-                    // hashed canonical m-mers at the U*64 + 15 start positions of this group ...
-                    uint32_t P[U + 1], S[U];
-                    const uint32_t pmax = sh + nb - (uint32_t)mlen; // last m-mer start inside the segment
-#pragma unroll
-                    for (int j = 0; j <= U; j++) {
-                        uint32_t p = sh + t0 + (uint32_t)j * 64u + lane;
-                        p = p < pmax ? p : pmax; // positions past the end never belong to a valid k-mer
+                    { // the win-1 m-mers behind the last k-mer of the group
+                        uint32_t p = sh + t0 + (uint32_t)U * 64u + lane;
+                        p = p < pmax ? p : pmax;
                         const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
                         const uint64_t A = ((uint64_t)W[w0] << 32) | W[w0 + 1];
-                        const uint32_t f = (uint32_t)((A << o2) >> (64 - 2 * mlen));
-                        const uint32_t h = kid_mmer_hash(f, mlen);
-                        P[j] = kid_row_prefix_min(h);
-                        if (j < U) S[j] = kid_row_suffix_min(h);
+                        P[U] = kid_row_prefix_min(kid_mmer_hash((uint32_t)((A << o2) >> (64 - 2 * mlen)), mlen));
                     }
                     // ... and their minimum over every window a[p..p+win-1].  With q = p mod 16: the window
                     // leaves its 16-lane row iff q + win > 16, then it is min(S[p], P[p+win-1]); inside
