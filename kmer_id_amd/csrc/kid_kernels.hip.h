@@ -28,6 +28,9 @@ typedef uint32_t kid_u4 __attribute__((ext_vector_type(4)));
 #ifndef KID_NT
 #define KID_NT 1
 #endif
+#ifndef KID_PREFETCH
+#define KID_PREFETCH 1 // software prefetch of the next read (descriptor two reads ahead, packed words one): ~1 %
+#endif
 #ifndef KID_PAIR
 #define KID_PAIR 0
 #endif
@@ -317,6 +320,7 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
     uint32_t n_hits = 0, n_reads = 0;      // wave-uniform
     uint32_t pend_t = 0, pend_n = 0;       // !HIST: run-length buffer in front of the global gcount atomics
 
+#if KID_PREFETCH
     // Software pipeline over the reads of this wave: the descriptor is fetched two reads ahead and
     // the first packed segment one read ahead, so that neither sits on the critical path of a read
     // (a wave is latency-bound: every read is a chain of dependent memory round trips).
@@ -358,6 +362,14 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
         d_cur = d_nxt;
         d_nxt = d_nn;
 
+#else
+    for (uint64_t r = gw; r < b.n; r += nw) {
+        const KidReadDesc d_cur = b.desc[r];
+        const uint64_t first = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(d_cur.first_base >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)d_cur.first_base);
+        const int64_t nk = (int64_t)__builtin_amdgcn_readfirstlane(d_cur.n_kmers);
+#endif
+
         uint32_t final_t = 0;
         uint4 frow = make_uint4(0, 0, 0, 0);
 
@@ -372,6 +384,7 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
             // ---- 1. stage the packed segment
             bool seg_clean;
             {
+#if KID_PREFETCH
                 uint32_t codes = st_codes, inv = st_inv;
                 if (seg != 0) { // long reads: later segments are fetched on the spot
                     codes = 0; inv = 0;
@@ -380,6 +393,13 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
                         inv = b.inval[c0 + lane];
                     }
                 }
+#else
+                uint32_t codes = 0, inv = 0;
+                if (lane < nchunks) {
+                    codes = b.codes[c0 + lane];
+                    inv = b.inval[c0 + lane];
+                }
+#endif
                 W[lane] = codes;
                 IM16[lane] = (uint16_t)inv;
                 if (lane < 2) { W[64 + lane] = 0; IM[32 + lane] = 0; }
