@@ -50,68 +50,105 @@ bool engine_open(Engine &e, const ProbeSet &ps, const std::vector<int32_t> &pare
     return true;
 }
 
-namespace {
-struct Pipe { // bounded hand-off of parsed batches from the reader thread to the GPU thread
+struct Prefetcher::Impl {
+    struct Slot {
+        std::deque<std::unique_ptr<ReadBatch>> q;
+        bool done = false, failed = false;
+        Fatal failure{0, ""};
+    };
+    std::vector<SourceOpener> files;
+    std::vector<Slot> slots;
+    std::vector<std::thread> pool;
     std::mutex m;
     std::condition_variable cv;
-    std::deque<std::unique_ptr<ReadBatch>> q;
-    bool done = false;
-    bool failed = false;
-    Fatal failure{0, ""};
-};
-}
+    size_t next_file = 0, batch_reads, batch_bases, depth;
+    bool stop = false;
 
-long long run_source(Engine &e, const std::function<std::unique_ptr<ReadSource>()> &open_source, ReadSaver &saver)
-{
-    Pipe pipe;
-    std::thread reader([&]() {
-        try {
-            std::unique_ptr<ReadSource> src = open_source();
-            if (src) {
-                for (;;) {
-                    std::unique_ptr<ReadBatch> b(new ReadBatch());
-                    if (!src->fill(*b, e.batch_reads, e.batch_bases)) break;
-                    std::unique_lock<std::mutex> lk(pipe.m);
-                    pipe.cv.wait(lk, [&] { return pipe.q.size() < 3; });
-                    pipe.q.push_back(std::move(b));
-                    pipe.cv.notify_all();
-                }
-                src->close();
+    void reader()
+    {
+        for (;;) {
+            size_t i;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (stop || next_file >= files.size()) return;
+                i = next_file++;
             }
-        } catch (const Fatal &f) {
-            std::lock_guard<std::mutex> lk(pipe.m);
-            pipe.failed = true;
-            pipe.failure = f;
-        }
-        std::lock_guard<std::mutex> lk(pipe.m);
-        pipe.done = true;
-        pipe.cv.notify_all();
-    });
-    long long n = 0;
-    std::vector<uint32_t> final_targ;
-    int rc = KID_OK;
-    for (;;) {
-        std::unique_ptr<ReadBatch> b;
-        {
-            std::unique_lock<std::mutex> lk(pipe.m);
-            pipe.cv.wait(lk, [&] { return !pipe.q.empty() || pipe.done; });
-            if (pipe.q.empty()) break;
-            b = std::move(pipe.q.front());
-            pipe.q.pop_front();
-            pipe.cv.notify_all();
-        }
-        if (rc != KID_OK) continue; // drain
-        final_targ.resize(b->size());
-        rc = kid_classify_batch(e.sample, b->bases.data(), b->offsets.data(), b->start.data(), b->stop.data(), b->size(),
-                                final_targ.data());
-        if (rc == KID_OK) {
-            saver.add_batch(*b, final_targ);
-            n += (long long)b->size();
+            try {
+                std::unique_ptr<ReadSource> src = files[i]();
+                if (src) {
+                    for (;;) {
+                        std::unique_ptr<ReadBatch> b(new ReadBatch());
+                        if (!src->fill(*b, batch_reads, batch_bases)) break;
+                        std::unique_lock<std::mutex> lk(m);
+                        cv.wait(lk, [&] { return stop || slots[i].q.size() < depth; });
+                        if (stop) return;
+                        slots[i].q.push_back(std::move(b));
+                        cv.notify_all();
+                    }
+                    src->close();
+                }
+            } catch (const Fatal &f) {
+                std::lock_guard<std::mutex> lk(m);
+                slots[i].failed = true;
+                slots[i].failure = f;
+            }
+            std::lock_guard<std::mutex> lk(m);
+            slots[i].done = true;
+            cv.notify_all();
         }
     }
-    reader.join();
-    if (rc != KID_OK) die_kid(rc);
-    if (pipe.failed) throw pipe.failure; // reads parsed before the failure were processed, as in the reference
+};
+
+Prefetcher::Prefetcher(std::vector<SourceOpener> files, int threads, size_t batch_reads, size_t batch_bases, size_t depth)
+    : impl_(new Impl())
+{
+    impl_->files = std::move(files);
+    impl_->slots = std::vector<Impl::Slot>(impl_->files.size());
+    impl_->batch_reads = batch_reads;
+    impl_->batch_bases = batch_bases;
+    impl_->depth = depth < 1 ? 1 : depth;
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > impl_->files.size()) threads = (int)impl_->files.size();
+    for (int t = 0; t < threads; t++) impl_->pool.emplace_back([this] { impl_->reader(); });
+}
+
+Prefetcher::~Prefetcher()
+{
+    {
+        std::lock_guard<std::mutex> lk(impl_->m);
+        impl_->stop = true;
+        impl_->cv.notify_all();
+    }
+    for (std::thread &t : impl_->pool) t.join();
+}
+
+std::unique_ptr<ReadBatch> Prefetcher::next(size_t index)
+{
+    Impl::Slot &s = impl_->slots[index];
+    std::unique_lock<std::mutex> lk(impl_->m);
+    impl_->cv.wait(lk, [&] { return !s.q.empty() || s.done; });
+    if (!s.q.empty()) {
+        std::unique_ptr<ReadBatch> b = std::move(s.q.front());
+        s.q.pop_front();
+        impl_->cv.notify_all();
+        return b;
+    }
+    if (s.failed) throw s.failure; // what was read before the failure has been handed out, as in the reference
+    return nullptr;
+}
+
+long long run_file(Engine &e, Prefetcher &pf, size_t index, ReadSaver &saver)
+{
+    long long n = 0;
+    std::vector<uint32_t> final_targ;
+    while (std::unique_ptr<ReadBatch> b = pf.next(index)) {
+        final_targ.resize(b->size());
+        int rc = kid_classify_batch(e.sample, b->bases.data(), b->offsets.data(), b->start.data(), b->stop.data(), b->size(),
+                                    final_targ.data());
+        if (rc != KID_OK) die_kid(rc);
+        saver.add_batch(*b, final_targ);
+        n += (long long)b->size();
+    }
     return n;
 }
 

@@ -32,9 +32,26 @@ void load_database(const std::string &tree_path, const std::string &probes_path,
 bool engine_open(Engine &e, const ProbeSet &ps, const std::vector<int32_t> &parent, int k, int log2_slots, int max_probes,
                  unsigned flags, int device);
 
-// one input file: parse (+ trim) on a reader thread, classify batch by batch on the caller's thread.
-// Returns the number of reads handed to process_read (the reference's tct increment).
-long long run_source(Engine &e, const std::function<std::unique_ptr<ReadSource>()> &open_source, ReadSaver &saver);
+// The input files of a run, parsed (+ trimmed) ahead of their turn on a small pool of reader threads:
+// gzip inflate + parsing is the slow half of the program (~1 M reads/s per core) and files are
+// independent until their reads reach the counters.  Batches are handed out strictly in file order;
+// a reader that runs ahead blocks once its file has `depth` batches queued, so memory stays bounded.
+// A failure while reading file i surfaces when the consumer gets to file i (the files before it have
+// been processed completely, like in the sequential reference).
+using SourceOpener = std::function<std::unique_ptr<ReadSource>()>;
+class Prefetcher {
+public:
+    Prefetcher(std::vector<SourceOpener> files, int threads, size_t batch_reads, size_t batch_bases, size_t depth = 3);
+    ~Prefetcher();
+    // next batch of file `index` (indices must be visited in increasing order); nullptr at its end
+    std::unique_ptr<ReadBatch> next(size_t index);
+private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+// classify every batch of file `index`; returns the number of reads handed to process_read
+long long run_file(Engine &e, Prefetcher &pf, size_t index, ReadSaver &saver);
 
 // --dry-run support (host stages only, no GPU): what WOULD be handed to the GPU, as text
 void dry_dump_db(FILE *f, const std::vector<int32_t> &parent, const ProbeSet &ps);

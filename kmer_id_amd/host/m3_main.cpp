@@ -35,20 +35,11 @@ static std::unique_ptr<ReadSource> open_by_suffix(const std::string &name, int k
     return nullptr;
 }
 
-static long long run_any(Engine &eng, const std::string &name, int k, ReadSaver &saver)
-{
-    bool missing = false;
-    if (ends_with(name, ".fasta.gz") && !ends_with(name, ".fastq.gz")) std::cout << "true" << std::endl; // process_fagz, :789
-    long long n = run_source(eng, [&]() { return open_by_suffix(name, k, &missing); }, saver);
-    if (missing) std::cout << "nark " << name << std::endl;
-    return n;
-}
-
 int main(int argc, char **argv)
 {
     std::string wdir, r1name, r2name;
-    int k = 30, log2_slots = 30, device = 0;
-    size_t batch_reads = 1 << 20;
+    int k = 30, log2_slots = 30, device = 0, threads = 2;
+    size_t batch_reads = 1 << 18;
     std::string dry_run; // --dry-run FILE: host stages only (no GPU), for the CPU test-suite
     std::string db_cache; // --db-cache FILE: binary cache of the parsed database
     for (int i = 1; i < argc; i++) {
@@ -62,6 +53,7 @@ int main(int argc, char **argv)
         if (a == "--device") device = atoi(v);
         if (a == "--batch-reads") batch_reads = (size_t)atoll(v);
         if (a == "--dry-run") dry_run = v;
+        if (a == "--threads") threads = atoi(v);
         if (a == "--db-cache") db_cache = v;
     }
     const std::string iname = wdir + "mitochondria_data.txt", tname = wdir + "mitochondria_tree.txt",
@@ -124,13 +116,33 @@ int main(int argc, char **argv)
 
         if (r1name.empty()) throw Fatal{134, "no -f1 given (std::out_of_range in the reference, :1080)"};
         std::cout << r1name.length() << " : " << r1name[r1name.length() - 1] << std::endl;
+        const bool have2 = r2name.length() > 1 && r2name != "none";
+        std::vector<std::string> names{r1name};
+        if (have2) names.push_back(r2name);
+        std::vector<char> missing(names.size(), 0);
+        std::vector<SourceOpener> files;
+        for (size_t f = 0; f < names.size(); f++) {
+            const std::string name = names[f];
+            char *flag = &missing[f];
+            files.push_back([name, k, flag]() {
+                bool m = false;
+                std::unique_ptr<ReadSource> src = open_by_suffix(name, k, &m);
+                *flag = m ? 1 : 0;
+                return src;
+            });
+        }
+        Prefetcher pf(std::move(files), threads, eng.batch_reads, eng.batch_bases);
         ReadSaver saver("", num_targ); // the reads file is commented out in this program (:612-621)
-        long long tct = run_any(eng, r1name, k, saver);
+        auto is_fagz = [](const std::string &n) { return ends_with(n, ".fasta.gz"); };
+        if (is_fagz(r1name)) std::cout << "true" << std::endl; // process_fagz, :789
+        long long tct = run_file(eng, pf, 0, saver);
+        if (missing[0]) std::cout << "nark " << r1name << std::endl;
         std::cout << tct << " reads loaded" << std::endl;
-        if (r2name.length() > 1 && r2name != "none") {
-            const bool fqgz = ends_with(r2name, ".fastq.gz");
-            tct += run_any(eng, r2name, k, saver);
-            if (fqgz) std::cout << tct << " reads loaded" << std::endl; // printed inside that branch too (:1107)
+        if (have2) {
+            if (is_fagz(r2name)) std::cout << "true" << std::endl;
+            tct += run_file(eng, pf, 1, saver);
+            if (missing[1]) std::cout << "nark " << r2name << std::endl;
+            if (ends_with(r2name, ".fastq.gz")) std::cout << tct << " reads loaded" << std::endl; // printed inside that branch too (:1107)
             std::cout << tct << " reads loaded" << std::endl;
         }
         finish_sample(eng, wdir + "result.txt");

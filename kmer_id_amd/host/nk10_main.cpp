@@ -8,7 +8,7 @@
 //
 // Options after the directory (all optional, defaults = the reference's compile-time constants):
 //   --db-dir DIR (./bact10/)  --ntar N (5982)  --k K (30)  --log2-slots L (30)  --device D (0)
-//   --batch-reads N (1048576)  --r1 SUFFIX (_R1_tr.fastq.gz)  --r2 SUFFIX (_R2_tr.fastq.gz)
+//   --batch-reads N (262144)  --threads T (4: reader threads parsing files ahead)  --r1 SUFFIX (_R1_tr.fastq.gz)  --r2 SUFFIX (_R2_tr.fastq.gz)
 //   --db-cache FILE  binary cache of the parsed database: read if valid, (re)written otherwise
 //   --dry-run FILE   host stages only (no GPU): parse the DB text files and the FASTQ files,
 //                    write what WOULD be handed to the GPU to FILE (used by the CPU test-suite)
@@ -31,8 +31,8 @@ using namespace kidhost;
 int main(int argc, char **argv)
 {
     std::string dname, db_dir = "./bact10/", e1 = "_R1_tr.fastq.gz", e2 = "_R2_tr.fastq.gz";
-    int ntar = 5982, k = 30, log2_slots = 30, device = 0;
-    size_t batch_reads = 1 << 20;
+    int ntar = 5982, k = 30, log2_slots = 30, device = 0, threads = 4;
+    size_t batch_reads = 1 << 18;
     std::string dry_run, db_cache;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -46,6 +46,7 @@ int main(int argc, char **argv)
         else if (a == "--log2-slots") log2_slots = atoi(val("--log2-slots"));
         else if (a == "--device") device = atoi(val("--device"));
         else if (a == "--batch-reads") batch_reads = (size_t)atoll(val("--batch-reads"));
+        else if (a == "--threads") threads = atoi(val("--threads"));
         else if (a == "--r1") e1 = val("--r1");
         else if (a == "--r2") e2 = val("--r2");
         else if (a == "--dry-run") dry_run = val("--dry-run");
@@ -127,6 +128,14 @@ int main(int argc, char **argv)
         }
         closedir(dir);
 
+        std::vector<SourceOpener> files;
+        for (const std::string &prefix : fnames)
+            for (const std::string &suffix : {e1, e2}) {
+                const std::string path = dname + prefix + suffix;
+                files.push_back([path, k]() { return std::unique_ptr<ReadSource>(new FastqStream(path, k)); });
+            }
+        Prefetcher pf(std::move(files), threads, eng.batch_reads, eng.batch_bases);
+        size_t fi = 0;
         for (const std::string &prefix : fnames) { // :1015-1045
             int rc = kid_sample_reset(eng.sample);
             if (rc != KID_OK) die_kid(rc);
@@ -134,9 +143,8 @@ int main(int argc, char **argv)
             long long tct = 0;
             {
                 ReadSaver saver(dname + prefix + "_reads.txt", ntar);
-                for (const std::string &suffix : {e1, e2}) {
-                    const std::string path = dname + prefix + suffix;
-                    tct += run_source(eng, [&]() { return std::unique_ptr<ReadSource>(new FastqStream(path, k)); }, saver);
+                for (int mate = 0; mate < 2; mate++) {
+                    tct += run_file(eng, pf, fi++, saver);
                     std::cout << tct << " reads loaded" << std::endl;
                 }
             }

@@ -40,8 +40,8 @@ static std::unique_ptr<ReadSource> open_by_suffix(const std::string &name, int k
 int main(int argc, char **argv)
 {
     std::string dname, wdir, jname, jdir, fdir;
-    int save_target = 0, k = 30, log2_slots = 30, device = 0;
-    size_t batch_reads = 1 << 20;
+    int save_target = 0, k = 30, log2_slots = 30, device = 0, threads = 4;
+    size_t batch_reads = 1 << 18;
     std::string dry_run; // --dry-run FILE: host stages only (no GPU), for the CPU test-suite
     std::string db_cache; // --db-cache FILE: binary cache of the parsed database
     for (int i = 1; i < argc; i++) {
@@ -56,6 +56,7 @@ int main(int argc, char **argv)
         if (a == "--device") device = atoi(v);
         if (a == "--batch-reads") batch_reads = (size_t)atoll(v);
         if (a == "--dry-run") dry_run = v;
+        if (a == "--threads") threads = atoi(v);
         if (a == "--db-cache") db_cache = v;
     }
     const std::string iname = wdir + dname + "_data.txt", tname = wdir + dname + "_tree.txt",
@@ -144,6 +145,23 @@ int main(int argc, char **argv)
         }
         ps = ProbeSet();
 
+        std::vector<SourceOpener> files;
+        std::vector<std::string> names;
+        for (int j = 0; j < num_jobs; j++)
+            for (int i = 0; i < jcounts[(size_t)j] && i < (int)fnames[(size_t)j].size(); i++) names.push_back(fnames[(size_t)j][(size_t)i]);
+        std::vector<char> missing(names.size(), 0);
+        for (size_t f = 0; f < names.size(); f++) {
+            const std::string name = names[f];
+            char *flag = &missing[f];
+            files.push_back([name, k, flag]() {
+                bool m = false;
+                std::unique_ptr<ReadSource> src = open_by_suffix(name, k, &m);
+                *flag = m ? 1 : 0;
+                return src;
+            });
+        }
+        Prefetcher pf(std::move(files), threads, eng.batch_reads, eng.batch_bases);
+        size_t fi = 0;
         for (int j = 0; j < num_jobs; j++) { // :1116-1164
             const std::string jstr = jnames[(size_t)j];
             int rc = kid_sample_reset(eng.sample);
@@ -153,12 +171,10 @@ int main(int argc, char **argv)
             {
                 ReadSaver saver(base + "_reads.txt", num_targ, save_target > 0 ? base + "_target_reads.txt" : "",
                                 (uint32_t)(save_target > 0 ? save_target : 0), save_target == 0);
-                for (int i = 0; i < jcounts[(size_t)j] && i < (int)fnames[(size_t)j].size(); i++) {
-                    const std::string r1name = fnames[(size_t)j][(size_t)i];
-                    std::cout << r1name << std::endl;
-                    bool missing = false;
-                    tct += run_source(eng, [&]() { return open_by_suffix(r1name, k, &missing); }, saver);
-                    if (missing) std::cout << "nark " << r1name << std::endl;
+                for (int i = 0; i < jcounts[(size_t)j] && i < (int)fnames[(size_t)j].size(); i++, fi++) {
+                    std::cout << names[fi] << std::endl;
+                    tct += run_file(eng, pf, fi, saver);
+                    if (missing[fi]) std::cout << "nark " << names[fi] << std::endl;
                 }
             }
             std::cout << tct << " reads loaded" << std::endl;
