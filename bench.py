@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--gather", type=int, default=1, help="also measure the random 16-byte gather ceiling")
     ap.add_argument("--geometry", choices=["minloc", "ref"], default="minloc",
                     help="table placement: minimizer-localised (default) or the reference's fmix64/triangular one")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                                                      "several ranks on one GPU: the merge then goes through host memory)")
     ap.add_argument("--xcheck", type=int, default=1,
                     help="classify the first batch on a second table built with the reference's geometry too: "
                          "full-size parity of the two placements + the reference-geometry probe count")
@@ -144,11 +146,15 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no HIP device is visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if args.backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     n_reads = 2 * args.pairs  # R1 + R2, classified independently (newkmer_10nx.cpp:1029-1031)
     want_cpu = (rank == 0 and world == 1 and args.cpu_reads > 0)
@@ -211,7 +217,7 @@ def main():
         ev[i][1].record(stream)
     # close the sample: ucount from the seen-bitmap (+ RCCL merge over the ranks)
     if world > 1:
-        g, u = merge_sample(sample, device)
+        g, u = merge_sample(sample, device if args.backend == "nccl" else torch.device("cpu"))
     else:
         g, u = sample.end()
     torch.cuda.synchronize(device)
@@ -220,7 +226,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -174,7 +174,7 @@ class Sample:
             check(self._lib.kid_sample_seen_export(self._h, byte_off, nbytes, _ptr(buf), 0))
             return buf
         check(self._lib.kid_sample_seen_export(self._h, byte_off, nbytes, C.c_void_p(dst_ptr), 1 if on_device else 0))
-        return None
+        return None  # dst_ptr may be a host pointer too (on_device=False)
 
     def seen_or(self, byte_off, src, nbytes=None, on_device=False):
         if isinstance(src, np.ndarray):

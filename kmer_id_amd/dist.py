@@ -41,15 +41,16 @@ def merge_counts(gcount, seen, count_slice, group=None, force_collectives=False)
 
 def merge_sample(sample, device, group=None, force_collectives=False):
     """Sample-level wrapper for the HIP path: -> (gcount, ucount) numpy int64 arrays."""
-    ntar = sample.ntar
+    device = torch.device(device)
+    on_dev = device.type == "cuda"  # False: rehearsal over gloo, the exchange goes through host memory
     g = torch.from_numpy(sample.gcount()).to(device)
     nbytes = sample.seen_bytes()
     seen = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    sample.seen_export(0, nbytes, dst_ptr=seen.data_ptr(), on_device=True)
+    sample.seen_export(0, nbytes, dst_ptr=seen.data_ptr(), on_device=on_dev)
 
     def count_slice(b0, b1, merged):
         if b1 - b0 != nbytes:  # fold the other ranks' bits of my slice into my bitmap, then count it
-            sample.seen_or(b0, merged.data_ptr(), nbytes=b1 - b0, on_device=True)
+            sample.seen_or(b0, merged.data_ptr(), nbytes=b1 - b0, on_device=on_dev)
         return torch.from_numpy(sample.ucount_range(b0 * 8, b1 * 8)).to(device)
 
     gt, ut = merge_counts(g, seen, count_slice, group, force_collectives)

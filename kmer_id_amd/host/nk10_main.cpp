@@ -34,6 +34,7 @@ int main(int argc, char **argv)
     int ntar = 5982, k = 30, log2_slots = 30, device = 0, threads = 4;
     size_t batch_reads = 1 << 18;
     std::string dry_run, db_cache;
+    bool parse_only = false; // --parse-only: run the reader pool over the directory without a GPU and report its rate
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&](const char *name) -> const char * {
@@ -51,6 +52,7 @@ int main(int argc, char **argv)
         else if (a == "--r2") e2 = val("--r2");
         else if (a == "--dry-run") dry_run = val("--dry-run");
         else if (a == "--db-cache") db_cache = val("--db-cache");
+        else if (a == "--parse-only") parse_only = true;
         else if (dname.empty()) dname = a;
         else { std::cerr << "nk10: unexpected argument " << a << "\n"; return 2; }
     }
@@ -104,6 +106,29 @@ int main(int argc, char **argv)
             return 0;
         }
 
+        if (parse_only) {
+            DIR *dd = opendir(dname.c_str());
+            std::vector<SourceOpener> files;
+            if (dd) {
+                while (struct dirent *ent = readdir(dd)) {
+                    std::string n1 = ent->d_name;
+                    size_t pos = n1.find(e1);
+                    if (pos == std::string::npos) continue;
+                    for (const std::string &suffix : {e1, e2}) {
+                        const std::string path = dname + n1.substr(0, pos) + suffix;
+                        files.push_back([path, k]() { return std::unique_ptr<ReadSource>(new FastqStream(path, k)); });
+                    }
+                }
+                closedir(dd);
+            }
+            const size_t nf = files.size();
+            Prefetcher pf(std::move(files), threads, batch_reads, (size_t)256 << 20);
+            long long n = 0, bases = 0;
+            for (size_t f = 0; f < nf; f++)
+                while (std::unique_ptr<ReadBatch> b = pf.next(f)) { n += (long long)b->size(); bases += (long long)b->bases.size(); }
+            std::cout << n << " reads, " << bases << " bases parsed" << std::endl;
+            return 0;
+        }
         Engine eng;
         eng.batch_reads = batch_reads;
         if (!engine_open(eng, ps, parent, k, log2_slots, 0, 0, device)) { // :256-260
