@@ -25,7 +25,11 @@ KID_HD uint64_t kid_fmix64(uint64_t k)
 KID_HD uint64_t kid_rev2(uint64_t x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    x = __brevll(x);
+    // bit-reverse each half, swap the halves, then swap the two bits of every group -- all 32-bit ops
+    uint32_t lo = __brev((uint32_t)(x >> 32)), hi = __brev((uint32_t)x);
+    lo = ((lo >> 1) & 0x55555555u) | ((lo & 0x55555555u) << 1);
+    hi = ((hi >> 1) & 0x55555555u) | ((hi & 0x55555555u) << 1);
+    return ((uint64_t)hi << 32) | lo;
 #else
     x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
     x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
@@ -33,9 +37,9 @@ KID_HD uint64_t kid_rev2(uint64_t x)
     x = ((x >> 8) & 0x00FF00FF00FF00FFULL) | ((x & 0x00FF00FF00FF00FFULL) << 8);
     x = ((x >> 16) & 0x0000FFFF0000FFFFULL) | ((x & 0x0000FFFF0000FFFFULL) << 16);
     x = (x >> 32) | (x << 32);
-#endif
     // a full bit reversal also swapped the two bits inside every group: undo that
     return ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+#endif
 }
 
 // The reference keeps two rolling keys (newkmer_10nx.cpp:480-519): keyF with the
@@ -134,7 +138,8 @@ KID_HD uint32_t kid_minloc_line(uint32_t g, uint32_t line_shift)
 // 16-bit fingerprint of a key kept in the line header; never 0 (0 = unused header slot)
 KID_HD uint32_t kid_key_fp(uint64_t key)
 {
-    const uint32_t f = ((uint32_t)key * 0x9E3779B1u + (uint32_t)(key >> 32) * 0x85EBCA77u) >> 16;
+    const uint32_t hi = (uint32_t)(key >> 32);
+    const uint32_t f = (((uint32_t)key ^ ((hi << 7) | (hi >> 25))) * 0x9E3779B1u) >> 16;
     return f ? f : 1u;
 }
 
