@@ -520,7 +520,13 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     const int grid = kid_grid_for(b.n, wpb, db->num_cu * 4);
     KidSampleDev sd{s->gcount, s->seen, s->stats};
     const bool rows = db->rows != nullptr;
-#define KID_LAUNCH(R, H, M) hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M>), dim3(grid), dim3(block), lds, stream, db->d, pk, sd, hist_words)
+#define KID_LAUNCH(R, H, M)                                                                                                    \
+    do {                                                                                                                       \
+        if (db->info.k == 30)                                                                                                  \
+            hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, 30>), dim3(grid), dim3(block), lds, stream, db->d, pk, sd, hist_words); \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, 0>), dim3(grid), dim3(block), lds, stream, db->d, pk, sd, hist_words);  \
+    } while (0)
     const bool ml = db->d.minloc != 0;
     if (rows && hist && ml) KID_LAUNCH(true, true, true);
     else if (rows && hist) KID_LAUNCH(true, true, false);

@@ -293,7 +293,7 @@ __global__ void kid_pack_kernel(const uint8_t *bases, uint64_t nchunks, uint32_t
 //      associative: newkmer_10nx.cpp:588-595) on wave-uniform registers;
 //   5. hit cells are marked in the sample's seen-bitmap (ucount, :596-603).
 // gcount is accumulated in an LDS histogram per workgroup and flushed once.
-template <int U, bool ROWS, bool HIST, bool MINLOC>
+template <int U, bool ROWS, bool HIST, bool MINLOC, int KFIX>
 __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db, const KidPacked b, const KidSampleDev s,
                                                             const uint32_t hist_words)
 {
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
         __syncthreads();
     }
 
-    const int k = db.k;
+    const int k = KFIX ? KFIX : db.k; // KFIX = 30: the reference's KSIZE folded into the shifts and masks
     const uint32_t win = (uint32_t)kid_min_window(k); // m-mers per k-mer window: 15 or 16
     const int mlen = kid_min_mlen(k);
     const uint64_t gw = (uint64_t)blockIdx.x * wpb + wib;
