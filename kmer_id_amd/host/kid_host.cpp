@@ -351,7 +351,8 @@ struct PlainTokenStream::Impl {
     std::ifstream fin;
 };
 
-PlainTokenStream::PlainTokenStream(const std::string &path, int k, bool fastq) : impl_(new Impl()), k_(k), fastq_(fastq)
+PlainTokenStream::PlainTokenStream(const std::string &path, int k, bool fastq, bool strip_cr)
+    : impl_(new Impl()), k_(k), fastq_(fastq), strip_cr_(strip_cr)
 {
     impl_->fin.open(path);
     open_ = (bool)impl_->fin;
@@ -369,7 +370,7 @@ bool PlainTokenStream::fill(ReadBatch &out, size_t max_reads, size_t max_bases)
             seq_.clear();
             break;
         }
-        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (strip_cr_ && !line.empty() && line.back() == '\r') line.pop_back();
         // the reference's own extraction: a line without a token leaves lseq_ as it was
         std::stringstream ls(line);
         ls >> lseq_;

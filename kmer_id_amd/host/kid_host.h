@@ -114,14 +114,15 @@ private:
 // line counts, and a blank line leaves the previous token in place (it is used again).
 class PlainTokenStream : public ReadSource {
 public:
-    PlainTokenStream(const std::string &path, int k, bool fastq);
+    // strip_cr: kmer_read_vf6 / kmer_read_m3 drop one trailing '\r' per line; newkmer_10nx's process_fa (:877-913) does not
+    PlainTokenStream(const std::string &path, int k, bool fastq, bool strip_cr = true);
     bool present() const { return open_; }
     bool fill(ReadBatch &out, size_t max_reads, size_t max_bases = (size_t)-1) override;
 private:
     struct Impl;
     std::shared_ptr<Impl> impl_;
     int k_;
-    bool fastq_, open_, eof_ = false;
+    bool fastq_, strip_cr_, open_, eof_ = false;
     int mod4_ = 0;
     std::string lseq_, seq_, acc_;
 };

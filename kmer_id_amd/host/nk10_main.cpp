@@ -9,6 +9,8 @@
 // Options after the directory (all optional, defaults = the reference's compile-time constants):
 //   --db-dir DIR (./bact10/)  --ntar N (5982)  --k K (30)  --log2-slots L (30)  --device D (0)
 //   --batch-reads N (262144)  --threads T (4: reader threads parsing files ahead)  --r1 SUFFIX (_R1_tr.fastq.gz)  --r2 SUFFIX (_R2_tr.fastq.gz)
+//   --fasta          the reference's compile-time FASTQ=0 mode (:28,:1032-1035): one plain FASTA file
+//                    <prefix><r1 suffix> per sample, read by process_fa (:877-913), no R2 file
 //   --db-cache FILE  binary cache of the parsed database: read if valid, (re)written otherwise
 //   --dry-run FILE   host stages only (no GPU): parse the DB text files and the FASTQ files,
 //                    write what WOULD be handed to the GPU to FILE (used by the CPU test-suite)
@@ -34,6 +36,7 @@ int main(int argc, char **argv)
     int ntar = 5982, k = 30, log2_slots = 30, device = 0, threads = 4;
     size_t batch_reads = 1 << 18;
     std::string dry_run, db_cache;
+    bool fasta_mode = false;
     bool parse_only = false; // --parse-only: run the reader pool over the directory without a GPU and report its rate
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -53,6 +56,7 @@ int main(int argc, char **argv)
         else if (a == "--dry-run") dry_run = val("--dry-run");
         else if (a == "--db-cache") db_cache = val("--db-cache");
         else if (a == "--parse-only") parse_only = true;
+        else if (a == "--fasta") fasta_mode = true;
         else if (dname.empty()) dname = a;
         else { std::cerr << "nk10: unexpected argument " << a << "\n"; return 2; }
     }
@@ -154,23 +158,43 @@ int main(int argc, char **argv)
         closedir(dir);
 
         std::vector<SourceOpener> files;
-        for (const std::string &prefix : fnames)
+        std::vector<char> missing(fnames.size(), 0);
+        for (size_t f = 0; f < fnames.size(); f++) {
+            const std::string prefix = fnames[f];
+            if (fasta_mode) {
+                const std::string path = dname + prefix + e1;
+                char *flag = &missing[f];
+                files.push_back([path, k, flag]() {
+                    std::unique_ptr<PlainTokenStream> p(new PlainTokenStream(path, k, false, /*strip_cr=*/false));
+                    *flag = p->present() ? 0 : 1;
+                    return std::unique_ptr<ReadSource>(std::move(p));
+                });
+                continue;
+            }
             for (const std::string &suffix : {e1, e2}) {
                 const std::string path = dname + prefix + suffix;
                 files.push_back([path, k]() { return std::unique_ptr<ReadSource>(new FastqStream(path, k)); });
             }
+        }
         Prefetcher pf(std::move(files), threads, eng.batch_reads, eng.batch_bases);
         size_t fi = 0;
-        for (const std::string &prefix : fnames) { // :1015-1045
+        for (size_t f = 0; f < fnames.size(); f++) { // :1015-1045
+            const std::string &prefix = fnames[f];
             int rc = kid_sample_reset(eng.sample);
             if (rc != KID_OK) die_kid(rc);
             std::cout << prefix << std::endl;
             long long tct = 0;
             {
                 ReadSaver saver(dname + prefix + "_reads.txt", ntar);
-                for (int mate = 0; mate < 2; mate++) {
+                if (fasta_mode) {
                     tct += run_file(eng, pf, fi++, saver);
+                    if (missing[f]) std::cout << "nark " << dname + prefix + e1 << std::endl;
                     std::cout << tct << " reads loaded" << std::endl;
+                } else {
+                    for (int mate = 0; mate < 2; mate++) {
+                        tct += run_file(eng, pf, fi++, saver);
+                        std::cout << tct << " reads loaded" << std::endl;
+                    }
                 }
             }
             finish_sample(eng, dname + prefix + "_result.txt");

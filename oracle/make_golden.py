@@ -464,9 +464,39 @@ def make_e2e_m3():
     print("e2e_m3:", sorted(os.listdir(outdir)))
 
 
+def make_e2e_fasta():
+    """newkmer_10nx compiled with FASTQ = 0: <prefix>_R1.fasta per sample through process_fa"""
+    rng = np.random.default_rng(13)
+    parent, cnt = synth.load_taxonomy("bact10")
+    cum = synth.cumulative(synth.scaled_counts(cnt, E2E_SCALE))
+    keys, targets = synth.db_keys(cum, K)
+    cwd = tempfile.mkdtemp(prefix="fa_")
+    setup_db_dir(cwd, parent, keys, targets)
+    fq = os.path.join(cwd, "fa") + "/"
+    os.makedirs(fq)
+    tmpd = tempfile.mkdtemp()
+    _write_inputs(tmpd, rng, keys, with_u=False)
+    shutil.copy(os.path.join(tmpd, "c.fasta"), fq + "X_R1.fasta")
+    recs = _mixed_records(rng, keys, 150, with_u=False)
+    with open(fq + "Y_R1.fasta", "w") as fh:
+        fh.write("".join(">%s\n%s\n" % (a, s) for a, s, _ in recs))
+    out = run_ref("nk10_ref_fasta_small", cwd, fq)
+    outdir = os.path.join(GOLD, "e2e_fasta")
+    shutil.rmtree(outdir, ignore_errors=True)
+    os.makedirs(outdir)
+    for f in sorted(os.listdir(fq)):
+        shutil.copy(fq + f, os.path.join(outdir, f))
+    with open(os.path.join(outdir, "stdout.txt"), "w") as fh:
+        fh.write(out.replace(fq, "<DIR>"))
+    shutil.rmtree(cwd); shutil.rmtree(tmpd)
+    print("e2e_fasta:", sorted(os.listdir(outdir)))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["kat", "small", "seeded", "vf6", "m3"]
+    what = sys.argv[1:] or ["kat", "small", "seeded", "vf6", "m3", "fasta"]
+    if "fasta" in what:
+        make_e2e_fasta()
     if "vf6" in what:
         make_e2e_vf6()
     if "m3" in what:

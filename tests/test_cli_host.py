@@ -211,3 +211,21 @@ def test_db_cache_round_trip(nk10, tmp_path):
     third, _ = run("third")
     assert third != first and b"PROBES 1000 1000" in third
     assert os.path.getsize(cache) == 64 + 4 * 5982 + 12 * 1000
+
+
+@pytest.mark.gpu
+def test_nk10_fasta_mode(nk10, gold_dir, tmp_path):
+    """the reference's FASTQ = 0 build (plain FASTA through process_fa, one file per sample)"""
+    src = os.path.join(gold_dir, "e2e_fasta")
+    cwd = str(tmp_path)
+    make_db_dir(cwd, 2e-4)
+    fa = os.path.join(cwd, "fa"); os.makedirs(fa)
+    for f in os.listdir(src):
+        if f.endswith(".fasta"):
+            shutil.copy(os.path.join(src, f), fa)
+    r = subprocess.run([nk10, fa + "/", "--fasta", "--r1", "_R1.fasta", "--log2-slots", "22", "--batch-reads", "41"], cwd=cwd,
+                       stdout=subprocess.PIPE, check=True)
+    for prefix in ("X", "Y"):
+        for suffix in ("_result.txt", "_reads.txt"):
+            assert filecmp.cmp(os.path.join(fa, prefix + suffix), os.path.join(src, prefix + suffix), shallow=False), prefix + suffix
+    assert sorted(r.stdout.decode().replace(fa + "/", "<DIR>").splitlines()) == sorted(open(os.path.join(src, "stdout.txt")).read().splitlines())
