@@ -105,6 +105,14 @@ __device__ __forceinline__ uint32_t kid_hdr_cand(const uint4 &h, uint32_t fp)
     return (((a - one) & ~a) & top) | ((((b - one) & ~b) & top) >> 1) | ((((c - one) & ~c) & top) >> 2) |
            ((((d - one) & ~d) & top) >> 3);
 }
+// the same question as a yes/no, written as seven 16-bit compares: hipcc turns them into
+// v_cmp_eq_u16 with sub-dword operand selects, whose lane masks combine on the scalar unit
+__device__ __forceinline__ bool kid_hdr_any(const uint4 &h, uint32_t fp)
+{
+    const uint16_t f = (uint16_t)fp;
+    return ((uint16_t)h.x == f) | ((uint16_t)(h.x >> 16) == f) | ((uint16_t)h.y == f) | ((uint16_t)(h.y >> 16) == f) |
+           ((uint16_t)h.z == f) | ((uint16_t)(h.z >> 16) == f) | ((uint16_t)h.w == f);
+}
 __device__ __forceinline__ uint32_t kid_cand_entry(uint32_t bit) // bit index from kid_hdr_cand -> entry 0..6
 {
     return 2u * (15u - (bit & 15u)) + (bit >> 4);
@@ -485,16 +493,16 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
 #pragma unroll
                     for (int u = 0; u < U; u++) {
                         fp[u] = kid_key_fp(key[u]);
-                        mm[u] = act[u] ? kid_hdr_cand(hd[u], fp[u]) : 0u;
                         step[u] = act[u] ? 1u : 0u;
-                        more |= act[u] && (mm[u] != 0 || (hd[u].w >> 16) >= KID_HDR_FULL);
+                        mm[u] = (act[u] && (kid_hdr_any(hd[u], fp[u]) || (hd[u].w >> 16) >= KID_HDR_FULL)) ? 1u : 0u;
+                        more |= mm[u] != 0;
                     }
                     if (more) { // ~1 % of the lanes: fingerprint matches (hits) and chained lines
 #pragma unroll
                         for (int u = 0; u < U; u++) {
-                            bool go = act[u] && (mm[u] != 0 || (hd[u].w >> 16) >= KID_HDR_FULL);
+                            bool go = mm[u] != 0;
                             uint4 h = hd[u];
-                            uint32_t m = mm[u], ln = line[u];
+                            uint32_t m = go ? kid_hdr_cand(h, fp[u]) : 0u, ln = line[u];
                             while (go) {
                                 if (m) {
                                     const uint32_t j = kid_cand_entry((uint32_t)__builtin_ctz(m));
