@@ -523,9 +523,9 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
 #define KID_LAUNCH(R, H, M)                                                                                                    \
     do {                                                                                                                       \
         if (db->info.k == 30)                                                                                                  \
-            hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, 30>), dim3(grid), dim3(block), lds, stream, db->d, pk, sd, hist_words); \
+            hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, 30>), dim3(grid), dim3(block), lds, stream, db->d, pk, sd, hist_words, pk.desc); \
         else                                                                                                                   \
-            hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, 0>), dim3(grid), dim3(block), lds, stream, db->d, pk, sd, hist_words);  \
+            hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, 0>), dim3(grid), dim3(block), lds, stream, db->d, pk, sd, hist_words, pk.desc);  \
     } while (0)
     const bool ml = db->d.minloc != 0;
     if (rows && hist && ml) KID_LAUNCH(true, true, true);

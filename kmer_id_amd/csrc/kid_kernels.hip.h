@@ -28,9 +28,6 @@ typedef uint32_t kid_u4 __attribute__((ext_vector_type(4)));
 #ifndef KID_NT
 #define KID_NT 1
 #endif
-#ifndef KID_PREFETCH
-#define KID_PREFETCH 1 // software prefetch of the next read (descriptor two reads ahead, packed words one): ~1 %
-#endif
 #ifndef KID_PAIR
 #define KID_PAIR 0
 #endif
@@ -303,8 +300,11 @@ __global__ void kid_pack_kernel(const uint8_t *bases, uint64_t nchunks, uint32_t
 // gcount is accumulated in an LDS histogram per workgroup and flushed once.
 template <int U, bool ROWS, bool HIST, bool MINLOC, int KFIX>
 __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db, const KidPacked b, const KidSampleDev s,
-                                                            const uint32_t hist_words)
+                                                            const uint32_t hist_words,
+                                                            const KidReadDesc *__restrict__ const descs)
 {
+    // (descs == b.desc, passed once more as a restrict-qualified argument: the wave-uniform
+    //  descriptor loads then become scalar loads, which stay in flight until first use)
     extern __shared__ uint32_t kid_smem[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform
@@ -328,281 +328,266 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
     uint32_t n_hits = 0, n_reads = 0;      // wave-uniform
     uint32_t pend_t = 0, pend_n = 0;       // !HIST: run-length buffer in front of the global gcount atomics
 
-#if KID_PREFETCH
-    // Software pipeline over the reads of this wave: the descriptor is fetched two reads ahead and
-    // the first packed segment one read ahead, so that neither sits on the critical path of a read
-    // (a wave is latency-bound: every read is a chain of dependent memory round trips).
-    KidReadDesc d_cur, d_nxt;
-    d_cur.first_base = 0; d_cur.n_kmers = 0; d_cur.pad = 0;
-    d_nxt = d_cur;
-    if (gw < b.n) d_cur = b.desc[gw];
-    if (gw + nw < b.n) d_nxt = b.desc[gw + nw];
-    uint32_t pf_codes = 0, pf_inv = 0;
-    {
-        const int32_t nk0 = d_cur.n_kmers;
-        const uint32_t sg = nk0 < KID_SEG_KMERS ? (uint32_t)(nk0 > 0 ? nk0 : 0) : KID_SEG_KMERS;
-        const uint32_t nch = nk0 > 0 ? (((uint32_t)d_cur.first_base & 15u) + sg + (uint32_t)k - 1u + 15u) >> 4 : 0u;
-        if (lane < nch) {
-            pf_codes = b.codes[(d_cur.first_base >> 4) + lane];
-            pf_inv = b.inval[(d_cur.first_base >> 4) + lane];
-        }
-    }
+    // ---- everything that happens to one read, given its descriptor and its first packed segment
+    // `prefetch` issues the loads for the reads behind this one; it is called right after this read's
+    // header loads went out (not before the loops: the compiler drains vmcnt in front of a loop)
+    auto process_read = [&](const uint64_t r, const uint64_t first, const int64_t nk, const uint32_t st_codes,
+                            const uint32_t st_inv, auto &&prefetch) {
+        bool prefetched = false;
+            uint32_t final_t = 0;
+            uint4 frow = make_uint4(0, 0, 0, 0);
 
-    for (uint64_t r = gw; r < b.n; r += nw) {
-        const uint64_t first = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(d_cur.first_base >> 32)) << 32) |
-                               (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)d_cur.first_base);
-        const int64_t nk = (int64_t)__builtin_amdgcn_readfirstlane(d_cur.n_kmers);
-        const uint32_t st_codes = pf_codes, st_inv = pf_inv; // first segment of this read, already here
-        // issue the loads for the reads behind this one
-        KidReadDesc d_nn;
-        d_nn.first_base = 0; d_nn.n_kmers = 0; d_nn.pad = 0;
-        if (r + 2 * nw < b.n) d_nn = b.desc[r + 2 * nw];
-        pf_codes = 0; pf_inv = 0;
-        {
-            const int32_t nk1 = d_nxt.n_kmers;
-            const uint32_t sg = nk1 < KID_SEG_KMERS ? (uint32_t)(nk1 > 0 ? nk1 : 0) : KID_SEG_KMERS;
-            const uint32_t nch = nk1 > 0 ? (((uint32_t)d_nxt.first_base & 15u) + sg + (uint32_t)k - 1u + 15u) >> 4 : 0u;
-            if (lane < nch) {
-                pf_codes = b.codes[(d_nxt.first_base >> 4) + lane];
-                pf_inv = b.inval[(d_nxt.first_base >> 4) + lane];
-            }
-        }
-        d_cur = d_nxt;
-        d_nxt = d_nn;
+            for (int64_t seg = 0; seg < nk; seg += KID_SEG_KMERS) {
+                const uint32_t segk = (uint32_t)((nk - seg) < KID_SEG_KMERS ? (nk - seg) : KID_SEG_KMERS);
+                const uint64_t b0 = first + (uint64_t)seg; // first base of the segment
+                const uint32_t nb = segk + (uint32_t)k - 1;
+                const uint64_t c0 = b0 >> 4;
+                const uint32_t sh = (uint32_t)(b0 & 15ull);
+                const uint32_t nchunks = (sh + nb + 15u) >> 4; // <= 64
 
-#else
-    for (uint64_t r = gw; r < b.n; r += nw) {
-        const KidReadDesc d_cur = b.desc[r];
-        const uint64_t first = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(d_cur.first_base >> 32)) << 32) |
-                               (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)d_cur.first_base);
-        const int64_t nk = (int64_t)__builtin_amdgcn_readfirstlane(d_cur.n_kmers);
-#endif
-
-        uint32_t final_t = 0;
-        uint4 frow = make_uint4(0, 0, 0, 0);
-
-        for (int64_t seg = 0; seg < nk; seg += KID_SEG_KMERS) {
-            const uint32_t segk = (uint32_t)((nk - seg) < KID_SEG_KMERS ? (nk - seg) : KID_SEG_KMERS);
-            const uint64_t b0 = first + (uint64_t)seg; // first base of the segment
-            const uint32_t nb = segk + (uint32_t)k - 1;
-            const uint64_t c0 = b0 >> 4;
-            const uint32_t sh = (uint32_t)(b0 & 15ull);
-            const uint32_t nchunks = (sh + nb + 15u) >> 4; // <= 64
-
-            // ---- 1. stage the packed segment
-            bool seg_clean;
-            {
-#if KID_PREFETCH
-                uint32_t codes = st_codes, inv = st_inv;
-                if (seg != 0) { // long reads: later segments are fetched on the spot
-                    codes = 0; inv = 0;
-                    if (lane < nchunks) {
-                        codes = b.codes[c0 + lane];
-                        inv = b.inval[c0 + lane];
+                // ---- 1. stage the packed segment
+                bool seg_clean;
+                {
+                    uint32_t codes = st_codes, inv = st_inv;
+                    if (seg != 0) { // long reads: later segments are fetched on the spot
+                        codes = 0; inv = 0;
+                        if (lane < nchunks) {
+                            codes = b.codes[c0 + lane];
+                            inv = b.inval[c0 + lane];
+                        }
                     }
+                    W[lane] = codes;
+                    IM16[lane] = (uint16_t)inv;
+                    if (lane < 2) { W[64 + lane] = 0; IM[32 + lane] = 0; }
+                    seg_clean = (__ballot(inv != 0) == 0); // wave-uniform: no base of this segment resets a window
                 }
-#else
-                uint32_t codes = 0, inv = 0;
-                if (lane < nchunks) {
-                    codes = b.codes[c0 + lane];
-                    inv = b.inval[c0 + lane];
-                }
-#endif
-                W[lane] = codes;
-                IM16[lane] = (uint16_t)inv;
-                if (lane < 2) { W[64 + lane] = 0; IM[32 + lane] = 0; }
-                seg_clean = (__ballot(inv != 0) == 0); // wave-uniform: no base of this segment resets a window
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-            // ---- 2..5 per group of U*64 windows
-            for (uint32_t t0 = 0; t0 < segk; t0 += U * 64u) {
-                uint64_t key[U];
-                uint32_t hlo[U]; // reference geometry: first cell of the probe sequence; minloc: the minimizer
-                bool act[U];
-                uint32_t P[U + 1], S[U]; // minloc: row prefix / suffix minima of the hashed m-mers
-                const uint32_t pmax = sh + nb - (uint32_t)mlen; // last m-mer start inside the segment
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const uint32_t i = t0 + (uint32_t)u * 64u + lane;
-                    // one window extraction serves the k-mer AND the m-mer that starts at the same base;
-                    // lanes past the last k-mer still hash their m-mer (the windows of earlier lanes reach
-                    // 14 positions ahead), clamped to the last one that lies inside the segment
-                    uint32_t p = sh + i;
-                    p = MINLOC ? (p < pmax ? p : pmax) : sh + (i < segk ? i : 0u);
-                    const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
-                    const uint64_t A = ((uint64_t)W[w0] << 32) | W[w0 + 1];
-                    const uint64_t B = W[w0 + 2];
-                    const uint64_t x = (A << o2) | ((B << o2) >> 32);
-                    const uint64_t keyF = x >> (64 - 2 * k);
-                    bool valid = (i < segk);
-                    if (!seg_clean) { // rare: some base of the segment is not ACGTacgt
-                        const uint64_t im = (((uint64_t)IM[(p >> 5) + 1] << 32) | IM[p >> 5]) >> (p & 31u);
-                        valid = valid && ((im & ((1ull << k) - 1ull)) == 0);
-                    }
-                    key[u] = kid_canonical(keyF, k);
-                    if (!MINLOC) hlo[u] = (uint32_t)kid_fmix64(key[u]) & db.slot_mask;
-                    act[u] = valid;
-                    n_lookups += valid ? 1u : 0u;
-                    if (MINLOC) {
-                        const uint32_t h = kid_mmer_hash((uint32_t)(x >> (64 - 2 * mlen)), mlen);
-                        P[u] = kid_row_prefix_min(h);
-                        S[u] = kid_row_suffix_min(h);
-                    }
-                }
-                if (MINLOC) {
-                    { // the win-1 m-mers behind the last k-mer of the group
-                        uint32_t p = sh + t0 + (uint32_t)U * 64u + lane;
-                        p = p < pmax ? p : pmax;
+                // ---- 2..5 per group of U*64 windows
+                for (uint32_t t0 = 0; t0 < segk; t0 += U * 64u) {
+                    uint64_t key[U];
+                    uint32_t hlo[U]; // reference geometry: first cell of the probe sequence; minloc: the minimizer
+                    bool act[U];
+                    uint32_t P[U + 1], S[U]; // minloc: row prefix / suffix minima of the hashed m-mers
+                    const uint32_t pmax = sh + nb - (uint32_t)mlen; // last m-mer start inside the segment
+    #pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint32_t i = t0 + (uint32_t)u * 64u + lane;
+                        // one window extraction serves the k-mer AND the m-mer that starts at the same base;
+                        // lanes past the last k-mer still hash their m-mer (the windows of earlier lanes reach
+                        // 14 positions ahead), clamped to the last one that lies inside the segment
+                        uint32_t p = sh + i;
+                        p = MINLOC ? (p < pmax ? p : pmax) : sh + (i < segk ? i : 0u);
                         const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
                         const uint64_t A = ((uint64_t)W[w0] << 32) | W[w0 + 1];
-                        P[U] = kid_row_prefix_min(kid_mmer_hash((uint32_t)((A << o2) >> (64 - 2 * mlen)), mlen));
+                        const uint64_t B = W[w0 + 2];
+                        const uint64_t x = (A << o2) | ((B << o2) >> 32);
+                        const uint64_t keyF = x >> (64 - 2 * k);
+                        bool valid = (i < segk);
+                        if (!seg_clean) { // rare: some base of the segment is not ACGTacgt
+                            const uint64_t im = (((uint64_t)IM[(p >> 5) + 1] << 32) | IM[p >> 5]) >> (p & 31u);
+                            valid = valid && ((im & ((1ull << k) - 1ull)) == 0);
+                        }
+                        key[u] = kid_canonical(keyF, k);
+                        if (!MINLOC) hlo[u] = (uint32_t)kid_fmix64(key[u]) & db.slot_mask;
+                        act[u] = valid;
+                        n_lookups += valid ? 1u : 0u;
+                        if (MINLOC) {
+                            const uint32_t h = kid_mmer_hash((uint32_t)(x >> (64 - 2 * mlen)), mlen);
+                            P[u] = kid_row_prefix_min(h);
+                            S[u] = kid_row_suffix_min(h);
+                        }
                     }
-                    // ... and their minimum over every window a[p..p+win-1].  With q = p mod 16: the window
-                    // leaves its 16-lane row iff q + win > 16, then it is min(S[p], P[p+win-1]); inside
-                    // one row it is exactly the prefix P[p+win-1] (q = 0) or the suffix S[p] (win = 15, q = 1)
-                    const uint32_t src = (lane + win - 1u) & 63u;
-                    const uint32_t q16 = lane & 15u;
-                    uint32_t nxt = (uint32_t)__shfl((int)P[0], (int)src);
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const uint32_t same = nxt;
-                        nxt = (uint32_t)__shfl((int)P[u + 1], (int)src);
-                        const uint32_t pn = (lane + win - 1u < 64u) ? same : nxt;
-                        const uint32_t both = S[u] < pn ? S[u] : pn;
-                        hlo[u] = (q16 + win > 16u) ? both : (q16 == 0u ? pn : S[u]);
-                    }
-                }
-                uint32_t tgt[U], slot[U], step[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) { tgt[u] = 0; slot[u] = 0; step[u] = 0; }
-                if (MINLOC) {
-                    // one 16-byte header per lookup settles every absent key; lanes that share a
-                    // minimizer read the same header (one sector for all of them)
-                    uint4 hd[U];
-                    uint32_t mm[U], fp[U], line[U];
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        line[u] = kid_minloc_line(hlo[u], db.line_shift);
-                        hd[u] = make_uint4(0, 0, 0, 0);
-                        if (act[u]) hd[u] = kid_load_cell(db.table, line[u] * KID_LINE_CELLS);
-                    }
-                    bool more = false;
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        fp[u] = kid_key_fp(key[u]);
-                        step[u] = act[u] ? 1u : 0u;
-                        mm[u] = (act[u] && (kid_hdr_any(hd[u], fp[u]) || (hd[u].w >> 16) >= KID_HDR_FULL)) ? 1u : 0u;
-                        more |= mm[u] != 0;
-                    }
-                    if (more) { // ~1 % of the lanes: fingerprint matches (hits) and chained lines
-#pragma unroll
+                    if (MINLOC) {
+                        { // the win-1 m-mers behind the last k-mer of the group
+                            uint32_t p = sh + t0 + (uint32_t)U * 64u + lane;
+                            p = p < pmax ? p : pmax;
+                            const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
+                            const uint64_t A = ((uint64_t)W[w0] << 32) | W[w0 + 1];
+                            P[U] = kid_row_prefix_min(kid_mmer_hash((uint32_t)((A << o2) >> (64 - 2 * mlen)), mlen));
+                        }
+                        // ... and their minimum over every window a[p..p+win-1].  With q = p mod 16: the window
+                        // leaves its 16-lane row iff q + win > 16, then it is min(S[p], P[p+win-1]); inside
+                        // one row it is exactly the prefix P[p+win-1] (q = 0) or the suffix S[p] (win = 15, q = 1)
+                        const uint32_t src = (lane + win - 1u) & 63u;
+                        const uint32_t q16 = lane & 15u;
+                        uint32_t nxt = (uint32_t)__shfl((int)P[0], (int)src);
+    #pragma unroll
                         for (int u = 0; u < U; u++) {
-                            bool go = mm[u] != 0;
-                            uint4 h = hd[u];
-                            uint32_t m = go ? kid_hdr_cand(h, fp[u]) : 0u, ln = line[u];
-                            while (go) {
-                                if (m) {
-                                    const uint32_t j = kid_cand_entry((uint32_t)__builtin_ctz(m));
-                                    m &= m - 1;
-                                    const uint32_t idx = ln * KID_LINE_CELLS + 1u + j;
-                                    const uint4 c = kid_load_cell(db.table, idx);
+                            const uint32_t same = nxt;
+                            nxt = (uint32_t)__shfl((int)P[u + 1], (int)src);
+                            const uint32_t pn = (lane + win - 1u < 64u) ? same : nxt;
+                            const uint32_t both = S[u] < pn ? S[u] : pn;
+                            hlo[u] = (q16 + win > 16u) ? both : (q16 == 0u ? pn : S[u]);
+                        }
+                    }
+                    uint32_t tgt[U], slot[U], step[U];
+    #pragma unroll
+                    for (int u = 0; u < U; u++) { tgt[u] = 0; slot[u] = 0; step[u] = 0; }
+                    if (MINLOC) {
+                        // one 16-byte header per lookup settles every absent key; lanes that share a
+                        // minimizer read the same header (one sector for all of them)
+                        uint4 hd[U];
+                        uint32_t mm[U], fp[U], line[U];
+    #pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            line[u] = kid_minloc_line(hlo[u], db.line_shift);
+                            hd[u] = make_uint4(0, 0, 0, 0);
+                            if (act[u]) hd[u] = kid_load_cell(db.table, line[u] * KID_LINE_CELLS);
+                        }
+                        if (!prefetched) { prefetch(); prefetched = true; }
+                        bool more = false;
+    #pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            fp[u] = kid_key_fp(key[u]);
+                            step[u] = act[u] ? 1u : 0u;
+                            mm[u] = (act[u] && (kid_hdr_any(hd[u], fp[u]) || (hd[u].w >> 16) >= KID_HDR_FULL)) ? 1u : 0u;
+                            more |= mm[u] != 0;
+                        }
+                        if (more) { // ~1 % of the lanes: fingerprint matches (hits) and chained lines
+    #pragma unroll
+                            for (int u = 0; u < U; u++) {
+                                bool go = mm[u] != 0;
+                                uint4 h = hd[u];
+                                uint32_t m = go ? kid_hdr_cand(h, fp[u]) : 0u, ln = line[u];
+                                while (go) {
+                                    if (m) {
+                                        const uint32_t j = kid_cand_entry((uint32_t)__builtin_ctz(m));
+                                        m &= m - 1;
+                                        const uint32_t idx = ln * KID_LINE_CELLS + 1u + j;
+                                        const uint4 c = kid_load_cell(db.table, idx);
+                                        step[u]++;
+                                        if (c.z != 0 && c.x == (uint32_t)key[u] && c.y == (uint32_t)(key[u] >> 32)) { tgt[u] = c.z; slot[u] = idx; go = false; }
+                                    } else if ((h.w >> 16) >= KID_HDR_FULL) {
+                                        ln = (ln + 1u) & db.line_mask;
+                                        h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
+                                        step[u]++;
+                                        m = kid_hdr_cand(h, fp[u]);
+                                    } else go = false;
+                                }
+                            }
+                        }
+                    } else {
+                        uint64_t rp[U];
+    #pragma unroll
+                        for (int u = 0; u < U; u++) rp[u] = 0;
+                        bool any = false;
+    #pragma unroll
+                        for (int u = 0; u < U; u++) any |= act[u];
+                        while (any) {
+                            uint4 c[U];
+                            uint32_t idx[U];
+    #pragma unroll
+                            for (int u = 0; u < U; u++) {
+                                idx[u] = (hlo[u] + (uint32_t)rp[u]) & db.slot_mask;
+                                c[u] = make_uint4(0, 0, 0, 0);
+                                if (act[u]) c[u] = kid_load_cell(db.table, idx[u]);
+                            }
+                            any = false;
+    #pragma unroll
+                            for (int u = 0; u < U; u++) {
+                                if (act[u]) {
                                     step[u]++;
-                                    if (c.z != 0 && c.x == (uint32_t)key[u] && c.y == (uint32_t)(key[u] >> 32)) { tgt[u] = c.z; slot[u] = idx; go = false; }
-                                } else if ((h.w >> 16) >= KID_HDR_FULL) {
-                                    ln = (ln + 1u) & db.line_mask;
-                                    h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
-                                    step[u]++;
-                                    m = kid_hdr_cand(h, fp[u]);
-                                } else go = false;
+                                    rp[u] += step[u];
+                                    if (c[u].z == 0) act[u] = false;
+                                    else if (c[u].x == (uint32_t)key[u] && c[u].y == (uint32_t)(key[u] >> 32)) {
+                                        tgt[u] = c[u].z; slot[u] = idx[u]; act[u] = false;
+                                    } else if (!(rp[u] < db.nslots) || (db.max_probes != 0 && step[u] >= db.max_probes)) act[u] = false;
+                                }
+                                any |= act[u];
                             }
                         }
                     }
-                } else {
-                    uint64_t rp[U];
-#pragma unroll
-                    for (int u = 0; u < U; u++) rp[u] = 0;
-                    bool any = false;
-#pragma unroll
-                    for (int u = 0; u < U; u++) any |= act[u];
-                    while (any) {
-                        uint4 c[U];
-                        uint32_t idx[U];
-#pragma unroll
-                        for (int u = 0; u < U; u++) {
-                            idx[u] = (hlo[u] + (uint32_t)rp[u]) & db.slot_mask;
-                            c[u] = make_uint4(0, 0, 0, 0);
-                            if (act[u]) c[u] = kid_load_cell(db.table, idx[u]);
+                    uint4 row[U];
+    #pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        n_probes += step[u];
+                        row[u] = make_uint4(0, 0, 0, 0);
+                        if (tgt[u] > 0) {
+                            if (ROWS) row[u] = db.rows[tgt[u]];
+                            if (tgt[u] > 1) atomicOr(&s.seen[slot[u] >> 5], 1u << (slot[u] & 31u));
                         }
-                        any = false;
-#pragma unroll
-                        for (int u = 0; u < U; u++) {
-                            if (act[u]) {
-                                step[u]++;
-                                rp[u] += step[u];
-                                if (c[u].z == 0) act[u] = false;
-                                else if (c[u].x == (uint32_t)key[u] && c[u].y == (uint32_t)(key[u] >> 32)) {
-                                    tgt[u] = c[u].z; slot[u] = idx[u]; act[u] = false;
-                                } else if (!(rp[u] < db.nslots) || (db.max_probes != 0 && step[u] >= db.max_probes)) act[u] = false;
+                    }
+                    // ---- 3. ordered fold over the hits (wave-uniform)
+    #pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        uint64_t m = __ballot(tgt[u] > 0);
+                        n_hits += (uint32_t)__popcll(m);
+                        while (m) {
+                            const int j = __builtin_ctzll(m);
+                            m &= m - 1;
+                            const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)tgt[u], j);
+                            if (x == final_t) continue; // msca(x,x) = x
+                            uint4 rx = make_uint4(0, 0, 0, 0);
+                            if (ROWS) {
+                                rx.x = (uint32_t)__builtin_amdgcn_readlane((int)row[u].x, j);
+                                rx.y = (uint32_t)__builtin_amdgcn_readlane((int)row[u].y, j);
+                                rx.z = (uint32_t)__builtin_amdgcn_readlane((int)row[u].z, j);
+                                rx.w = (uint32_t)__builtin_amdgcn_readlane((int)row[u].w, j);
                             }
-                            any |= act[u];
+                            if (final_t == 0) { final_t = x; frow = rx; continue; } // :592-595
+                            if (ROWS) {
+                                uint4 ro;
+                                final_t = kid_msca_rows(x, rx, final_t, frow, ro); // :588-591
+                                frow = ro;
+                            } else {
+                                final_t = kid_msca_climb(db, x, final_t);
+                            }
                         }
                     }
                 }
-                uint4 row[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    n_probes += step[u];
-                    row[u] = make_uint4(0, 0, 0, 0);
-                    if (tgt[u] > 0) {
-                        if (ROWS) row[u] = db.rows[tgt[u]];
-                        if (tgt[u] > 1) atomicOr(&s.seen[slot[u] >> 5], 1u << (slot[u] & 31u));
-                    }
-                }
-                // ---- 3. ordered fold over the hits (wave-uniform)
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    uint64_t m = __ballot(tgt[u] > 0);
-                    n_hits += (uint32_t)__popcll(m);
-                    while (m) {
-                        const int j = __builtin_ctzll(m);
-                        m &= m - 1;
-                        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)tgt[u], j);
-                        if (x == final_t) continue; // msca(x,x) = x
-                        uint4 rx = make_uint4(0, 0, 0, 0);
-                        if (ROWS) {
-                            rx.x = (uint32_t)__builtin_amdgcn_readlane((int)row[u].x, j);
-                            rx.y = (uint32_t)__builtin_amdgcn_readlane((int)row[u].y, j);
-                            rx.z = (uint32_t)__builtin_amdgcn_readlane((int)row[u].z, j);
-                            rx.w = (uint32_t)__builtin_amdgcn_readlane((int)row[u].w, j);
-                        }
-                        if (final_t == 0) { final_t = x; frow = rx; continue; } // :592-595
-                        if (ROWS) {
-                            uint4 ro;
-                            final_t = kid_msca_rows(x, rx, final_t, frow, ro); // :588-591
-                            frow = ro;
-                        } else {
-                            final_t = kid_msca_climb(db, x, final_t);
-                        }
-                    }
-                }
+                __builtin_amdgcn_wave_barrier(); // strip is rewritten by the next segment / read
             }
-            __builtin_amdgcn_wave_barrier(); // strip is rewritten by the next segment / read
-        }
 
-        n_reads++;
-        if (HIST) {
-            if (lane == 0) atomicAdd(&hist[final_t], 1u);
-        } else if (final_t == pend_t) {
-            pend_n++;
-        } else {
-            if (pend_n && lane == 0) atomicAdd(&s.gcount[pend_t], (unsigned long long)pend_n);
-            pend_t = final_t;
-            pend_n = 1;
-        }
-        if (lane == 0 && b.out_final) b.out_final[r] = final_t;
+            n_reads++;
+            if (HIST) {
+                if (lane == 0) atomicAdd(&hist[final_t], 1u);
+            } else if (final_t == pend_t) {
+                pend_n++;
+            } else {
+                if (pend_n && lane == 0) atomicAdd(&s.gcount[pend_t], (unsigned long long)pend_n);
+                pend_t = final_t;
+                pend_n = 1;
+            }
+            if (lane == 0 && b.out_final) b.out_final[r] = final_t;
+            if (!prefetched) prefetch();
+    };
+
+    // Software pipeline over the reads of this wave, unrolled by two with two named register sets
+    // (A, B) so that nothing is copied between stages: the descriptor of a read is requested two
+    // reads ahead and its first packed segment one read ahead, and the waits the compiler places in
+    // front of their first use land behind a whole read's worth of work (a wave is latency-bound:
+    // every read is a chain of dependent memory round trips).
+    auto fetch_desc = [&](uint64_t r, KidReadDesc &d) {
+        d.first_base = 0; d.n_kmers = 0; d.pad = 0;
+        if (r < b.n) d = descs[r];
+    };
+    auto fetch_words = [&](const KidReadDesc &d, uint32_t &codes, uint32_t &inv) {
+        // unconditional (the scratch arrays are padded by 64 entries): a fixed number of loads keeps the
+        // compiler's vmcnt bookkeeping exact, so the waits for older loads do not drain these
+        codes = b.codes[(d.first_base >> 4) + lane];
+        inv = b.inval[(d.first_base >> 4) + lane];
+    };
+    auto uniform64 = [](uint64_t v) {
+        return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+    };
+    KidReadDesc dA, dB;
+    uint32_t cA, iA, cB, iB;
+    fetch_desc(gw, dA);
+    fetch_desc(gw + nw, dB);
+    fetch_words(dA, cA, iA);
+    for (uint64_t r = gw; r < b.n; r += 2 * nw) {
+        // read r (set A); meanwhile the words of read r + nw and the descriptor of read r + 2 nw travel
+        const uint64_t firstA = uniform64(dA.first_base);
+        const int64_t nkA = (int64_t)__builtin_amdgcn_readfirstlane(dA.n_kmers);
+        process_read(r, firstA, nkA, cA, iA, [&]() { fetch_words(dB, cB, iB); fetch_desc(r + 2 * nw, dA); });
+        if (r + nw >= b.n) break;
+        // read r + nw (set B); the words of read r + 2 nw and the descriptor of read r + 3 nw travel
+        const uint64_t firstB = uniform64(dB.first_base);
+        const int64_t nkB = (int64_t)__builtin_amdgcn_readfirstlane(dB.n_kmers);
+        process_read(r + nw, firstB, nkB, cB, iB, [&]() { fetch_words(dA, cA, iA); fetch_desc(r + 3 * nw, dB); });
     }
     if (!HIST && pend_n && lane == 0) atomicAdd(&s.gcount[pend_t], (unsigned long long)pend_n);
 
