@@ -143,6 +143,12 @@ int kid_sample_end(kid_sample *s, int64_t *gcount, int64_t *ucount);
 /* {reads, k-mer lookups, table cells read, k-mer hits} so far (synchronises) */
 int kid_sample_stats(kid_sample *s, uint64_t out[4]);
 
+/* Kernel timing for benchmarks: when enabled, every batch records a HIP event pair around the
+ * kid_classify_kernel launch (on the launch stream).  kid_sample_kernel_time synchronises, adds up
+ * the elapsed times of the launches since the last call and returns their number.              */
+int kid_sample_set_timing(kid_sample *s, int enabled);
+int kid_sample_kernel_time(kid_sample *s, double *total_ms, uint64_t *launches);
+
 /* ---- multi-GPU merge helpers (reads sharded over ranks, DB replicated) ---------
  * ucount is |distinct DB k-mers hit| and is not additive over shards: ranks
  * exchange slices of the per-cell "seen" bitmap, OR them, and count their slice. */

@@ -163,6 +163,15 @@ class Sample:
         check(self._lib.kid_sample_stats(self._h, _ptr(out)))
         return {"reads": int(out[0]), "lookups": int(out[1]), "probes": int(out[2]), "hits": int(out[3])}
 
+    def set_timing(self, enabled=True):
+        check(self._lib.kid_sample_set_timing(self._h, 1 if enabled else 0))
+
+    def kernel_time(self):
+        """-> (total ms, launches) of kid_classify_kernel since the last call (HIP events on the launch stream)"""
+        ms, n = C.c_double(0), C.c_uint64(0)
+        check(self._lib.kid_sample_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def seen_bytes(self):
         n = C.c_uint64(0)
         check(self._lib.kid_sample_seen_bytes(self._h, C.byref(n)))

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/kmer_id_amd.h"
@@ -53,6 +54,8 @@ struct kid_sample {
     uint32_t *seen = nullptr;
     uint64_t seen_words = 0;
     hipStream_t stream = nullptr;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed; // around each classify launch, while timing is on
     // per-batch scratch of the device pipeline (prepare -> pack -> classify), grown on demand
     KidReadDesc *sc_desc = nullptr;
     uint64_t sc_desc_cap = 0;
@@ -426,6 +429,7 @@ extern "C" void kid_sample_destroy(kid_sample *s)
     if (s->ucount) hipFree(s->ucount);
     if (s->stats) hipFree(s->stats);
     if (s->seen) hipFree(s->seen);
+    for (auto &ev : s->timed) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     if (s->sc_desc) hipFree(s->sc_desc);
     if (s->sc_codes) hipFree(s->sc_codes);
     if (s->sc_inval) hipFree(s->sc_inval);
@@ -520,6 +524,12 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     const int grid = kid_grid_for(b.n, wpb, db->num_cu * 4);
     KidSampleDev sd{s->gcount, s->seen, s->stats};
     const bool rows = db->rows != nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (s->timing) {
+        KID_HIP(hipEventCreate(&ev0));
+        KID_HIP(hipEventCreate(&ev1));
+        KID_HIP(hipEventRecord(ev0, stream));
+    }
 #define KID_LAUNCH(R, H, M)                                                                                                    \
     do {                                                                                                                       \
         if (db->info.k == 30)                                                                                                  \
@@ -537,7 +547,38 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     else if (ml) KID_LAUNCH(false, false, true);
     else KID_LAUNCH(false, false, false);
 #undef KID_LAUNCH
+    if (s->timing) {
+        KID_HIP(hipEventRecord(ev1, stream));
+        s->timed.emplace_back(ev0, ev1);
+    }
     KID_HIP(hipGetLastError());
+    return KID_OK;
+}
+
+extern "C" int kid_sample_set_timing(kid_sample *s, int enabled)
+{
+    if (!s) return kid_fail(KID_ERR_ARG, "null sample");
+    s->timing = enabled != 0;
+    return KID_OK;
+}
+
+extern "C" int kid_sample_kernel_time(kid_sample *s, double *total_ms, uint64_t *launches)
+{
+    if (!s || !total_ms || !launches) return kid_fail(KID_ERR_ARG, "null argument");
+    int rc = kid_use_device(s->db->device);
+    if (rc != KID_OK) return rc;
+    KID_HIP(hipDeviceSynchronize());
+    double sum = 0;
+    for (auto &ev : s->timed) {
+        float ms = 0;
+        KID_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+        sum += ms;
+        hipEventDestroy(ev.first);
+        hipEventDestroy(ev.second);
+    }
+    *total_ms = sum;
+    *launches = s->timed.size();
+    s->timed.clear();
     return KID_OK;
 }
 
