@@ -550,3 +550,29 @@ def test_config5_fungal_vf6_250bp():
         assert np.array_equal(g, eg) and np.array_equal(u, eu)
         assert s.stats()["lookups"] == os_.stats()["lookups"]
         s.close(); db.close()
+
+
+@pytest.mark.parametrize("k", [15, 21, 24, 27, 29, 31])
+def test_other_kmer_lengths(k):
+    """k is a run-time parameter of the library (KSIZE = 30 in all shipped reference programs): the
+    minimizer placement is used for k >= 24 (m = k - 14, window 15; k = 31: m = 16, window 16), the
+    reference placement below that; the k = 30 kernel specialisation must not leak into other k"""
+    parent, cnt = synth.load_taxonomy("bact10")
+    cum = synth.cumulative(synth.scaled_counts(cnt, 5e-4))
+    keys, targets = synth.db_keys(cum, k, seed=0x100 + k)
+    odb = oracle_db(parent, keys, targets, 19, k=k)
+    db = KmerDB(keys, targets, parent, k=k, log2_slots=19)
+    assert db.info.geometry == (1 if k >= 24 else 0)
+    q = np.concatenate([keys[::7], keys[:3000] ^ np.uint64(1)])
+    assert np.array_equal(db.lookup(q), odb.get(q))
+    n, L = 8000, 151
+    bases = synth.reads(cum, parent, n, L, k, db_seed=0x100 + k, read_seed=k)
+    off = synth.fixed_offsets(n, L)
+    os_ = ob.OracleSample(odb)
+    exp = os_.classify(bases, off)
+    s = db.sample()
+    assert np.array_equal(s.classify(bases, off), exp)
+    g, u = s.end(); eg, eu = os_.counts()
+    assert np.array_equal(g, eg) and np.array_equal(u, eu)
+    assert s.stats()["lookups"] == os_.stats()["lookups"] and (exp > 1).sum() > n // 5
+    s.close(); db.close()
