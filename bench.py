@@ -108,7 +108,8 @@ def traffic_from_profile(args, info):
     TCC_EA0_RDREQ_128B x 128 B + 64-byte requests + WRITE_SIZE.  Only reported when the profile
     was taken on this exact workload; the live run does not collect counters."""
     path = os.path.join(ROOT, "profiles", "r01", "pmc_final.json")
-    if not os.path.exists(path) or args.scale != 1.0 or args.pairs != 1_000_000 or args.log2_slots != 30 or args.geometry != "minloc":
+    if (not os.path.exists(path) or args.scale != 1.0 or args.pairs != 1_000_000 or args.log2_slots != 30 or
+            args.geometry != "minloc" or args.read_len != 150):
         return None
     try:
         d = json.load(open(path))
@@ -129,6 +130,7 @@ def main():
     ap.add_argument("--cpu-reads", type=int, default=300_000, help="reads of the CPU baseline sample (0 = skip)")
     ap.add_argument("--batches", type=int, default=4, help="distinct resident read batches cycled over the steps")
     ap.add_argument("--gather", type=int, default=1, help="also measure the random 16-byte gather ceiling")
+    ap.add_argument("--read-len", type=int, default=150, help="read length (configs[1]: 150; configs[4]: 250)")
     ap.add_argument("--geometry", choices=["minloc", "ref"], default="minloc",
                     help="table placement: minimizer-localised (default) or the reference's fmix64/triangular one")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
@@ -137,6 +139,8 @@ def main():
                     help="classify the first batch on a second table built with the reference's geometry too: "
                          "full-size parity of the two placements + the reference-geometry probe count")
     args = ap.parse_args()
+    global READ_LEN
+    READ_LEN = args.read_len
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -287,8 +291,8 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": "bact10-synth DB (%d 30-mers on the real bact10 taxonomy, 2^%d-cell table resident in HBM), "
-                                   "%d synthetic 150 bp read pairs per GPU per step, reads resident in HBM" % (
-                                       info.n_entries, args.log2_slots, args.pairs),
+                                   "%d synthetic %d bp read pairs per GPU per step, reads resident in HBM" % (
+                                       info.n_entries, args.log2_slots, args.pairs, READ_LEN),
                        "db_scale": args.scale, "pairs_per_gpu_per_step": args.pairs, "read_len": READ_LEN, "k": K,
                        "sharding": "reads sharded over %d rank(s), DB replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
