@@ -57,6 +57,8 @@ struct kid_sample {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed; // around each classify launch, while timing is on
     // per-batch scratch of the device pipeline (prepare -> pack -> classify), grown on demand
+    KidRareArgs *d_rare = nullptr; // device copy, written once in kid_sample_begin (batch_max: by every batch)
+    uint32_t batch_seq = 0;
     KidReadDesc *sc_desc = nullptr;
     uint64_t sc_desc_cap = 0;
     uint32_t *sc_codes = nullptr;
@@ -430,6 +432,7 @@ extern "C" void kid_sample_destroy(kid_sample *s)
     if (s->stats) hipFree(s->stats);
     if (s->seen) hipFree(s->seen);
     for (auto &ev : s->timed) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    if (s->d_rare) hipFree(s->d_rare);
     if (s->sc_desc) hipFree(s->sc_desc);
     if (s->sc_codes) hipFree(s->sc_codes);
     if (s->sc_inval) hipFree(s->sc_inval);
@@ -451,7 +454,7 @@ extern "C" int kid_sample_reset(kid_sample *s)
     const size_t nt = (size_t)s->db->info.ntar;
     KID_HIP(hipMemset(s->gcount, 0, nt * 8));
     KID_HIP(hipMemset(s->ucount, 0, nt * 8));
-    KID_HIP(hipMemset(s->stats, 0, 64));
+    KID_HIP(hipMemset(s->stats, 0, 256));
     KID_HIP(hipMemset(s->seen, 0, s->seen_words * 4));
     KID_HIP(hipDeviceSynchronize());
     return KID_OK;
@@ -477,9 +480,14 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
     } while (0)
     KID_S_HIP(hipMalloc(&s->gcount, nt * 8));
     KID_S_HIP(hipMalloc(&s->ucount, nt * 8));
-    KID_S_HIP(hipMalloc(&s->stats, 64));
+    KID_S_HIP(hipMalloc(&s->stats, 256)); // [0..7] counters, [8..31] KID_PROFILE phase cycles
     KID_S_HIP(hipMalloc(&s->seen, s->seen_words * 4));
     KID_S_HIP(hipStreamCreate(&s->stream));
+    {
+        const KidRareArgs ra{s->gcount, s->stats, db->d.line_mask, 0u, 0ull};
+        KID_S_HIP(hipMalloc(&s->d_rare, sizeof(ra)));
+        KID_S_HIP(hipMemcpy(s->d_rare, &ra, sizeof(ra), hipMemcpyHostToDevice));
+    }
 #undef KID_S_HIP
     rc = kid_sample_reset(s);
     if (rc != KID_OK) { kid_sample_destroy(s); return rc; }
@@ -495,6 +503,7 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
 {
     kid_db *db = s->db;
     if (b.n == 0) return KID_OK;
+    if (b.n > 0x7FFFFFFFull) return kid_fail(KID_ERR_ARG, "at most 2^31-1 reads per batch");
     const uint64_t nchunks = (bases_nbytes + 15) / 16;
     if (b.n > s->sc_desc_cap) {
         if (s->sc_desc) hipFree(s->sc_desc);
@@ -511,16 +520,17 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
         s->sc_chunks_cap = nchunks;
     }
     hipLaunchKernelGGL(kid_prepare_kernel, dim3(kid_grid_for(b.n, 256, db->num_cu * 8)), dim3(256), 0, stream, b, db->info.k,
-                       s->sc_desc, s->stats);
+                       s->sc_desc, s->stats, s->d_rare, ++s->batch_seq);
     if (nchunks)
         hipLaunchKernelGGL(kid_pack_kernel, dim3(kid_grid_for(nchunks, 256, db->num_cu * 16)), dim3(256), 0, stream, b.bases,
                            nchunks, db->d.u_is_t, s->sc_codes, s->sc_inval);
     KidPacked pk{s->sc_codes, s->sc_inval, s->sc_desc, b.out_final, b.n};
     const int block = 512, wpb = block / 64;
     const uint32_t ntar = (uint32_t)db->info.ntar;
-    const bool hist = (ntar * 4u <= 36u * 1024u);
-    const uint32_t hist_words = hist ? ((ntar + 3u) & ~3u) : 0u;
-    const size_t lds = ((size_t)hist_words + (size_t)wpb * KID_WAVE_LDS_WORDS) * 4;
+    // the gcount histogram lives in LDS while four workgroups per CU (160 KiB) still fit beside the waves' strips
+    const uint32_t hist_words = (ntar + 3u) & ~3u;
+    const bool hist = (hist_words + wpb * KID_WAVE_LDS_WORDS) * 4u <= 40u * 1024u;
+    const bool hist_pair = (hist_words + wpb * KID_PAIR_LDS_WORDS) * 4u <= 40u * 1024u;
     const int grid = kid_grid_for(b.n, wpb, db->num_cu * 4);
     KidSampleDev sd{s->gcount, s->seen, s->stats};
     const bool rows = db->rows != nullptr;
@@ -530,14 +540,28 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
         KID_HIP(hipEventCreate(&ev1));
         KID_HIP(hipEventRecord(ev0, stream));
     }
+#define KID_LAUNCH1(R, H, M, KF, PK)                                                                                            \
+    hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, KF, PK>), dim3(grid), dim3(block),                                     \
+                       (((H) ? hist_words : 0u) + (size_t)wpb * ((PK) ? KID_PAIR_LDS_WORDS : KID_WAVE_LDS_WORDS)) * 4, stream,  \
+                       db->d, pk, sd, (H) ? hist_words : 0u, pk.desc, s->d_rare)
 #define KID_LAUNCH(R, H, M)                                                                                                    \
     do {                                                                                                                       \
-        if (db->info.k == 30)                                                                                                  \
-            hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, 30>), dim3(grid), dim3(block), lds, stream, db->d, pk, sd, hist_words, pk.desc); \
-        else                                                                                                                   \
-            hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, 0>), dim3(grid), dim3(block), lds, stream, db->d, pk, sd, hist_words, pk.desc);  \
+        if (db->info.k == 30) KID_LAUNCH1(R, H, M, 30, false);                                                                 \
+        else KID_LAUNCH1(R, H, M, 0, false);                                                                                   \
+    } while (0)
+    // the minimizer-localised table has two kernels per batch (see kid_classify_kernel): pair loop, general loops
+#define KID_LAUNCH_PK(R, H)                                                                                                    \
+    do {                                                                                                                       \
+        if (db->info.k == 30) KID_LAUNCH1(R, H, true, 30, true);                                                               \
+        else KID_LAUNCH1(R, H, true, 0, true);                                                                                 \
     } while (0)
     const bool ml = db->d.minloc != 0;
+    if (ml && KID_PAIRS) {
+        if (rows && hist_pair) KID_LAUNCH_PK(true, true);
+        else if (rows) KID_LAUNCH_PK(true, false);
+        else if (hist_pair) KID_LAUNCH_PK(false, true);
+        else KID_LAUNCH_PK(false, false);
+    }
     if (rows && hist && ml) KID_LAUNCH(true, true, true);
     else if (rows && hist) KID_LAUNCH(true, true, false);
     else if (rows && ml) KID_LAUNCH(true, false, true);
@@ -546,6 +570,8 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     else if (hist) KID_LAUNCH(false, true, false);
     else if (ml) KID_LAUNCH(false, false, true);
     else KID_LAUNCH(false, false, false);
+#undef KID_LAUNCH_PK
+#undef KID_LAUNCH1
 #undef KID_LAUNCH
     if (s->timing) {
         KID_HIP(hipEventRecord(ev1, stream));
@@ -783,6 +809,17 @@ extern "C" int kid_sample_stats(kid_sample *s, uint64_t out[4])
     unsigned long long st[8];
     KID_HIP(hipMemcpy(st, s->stats, 64, hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; i++) out[i] = st[i];
+    return KID_OK;
+}
+
+// development aid (not in the public header): the per-phase cycle sums a -DKID_PROFILE build collects
+extern "C" int kid_sample_debug_counters(kid_sample *s, uint64_t out[24])
+{
+    if (!s || !out) return kid_fail(KID_ERR_ARG, "null argument");
+    int rc = kid_use_device(s->db->device);
+    if (rc != KID_OK) return rc;
+    KID_HIP(hipDeviceSynchronize());
+    KID_HIP(hipMemcpy(out, s->stats + 8, 24 * 8, hipMemcpyDeviceToHost));
     return KID_OK;
 }
 

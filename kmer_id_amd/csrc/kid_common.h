@@ -116,6 +116,15 @@ KID_HD uint32_t kid_mmer_hash(uint32_t f, int m)
     return h;
 }
 
+// the same with the reverse complement r of f already at hand
+KID_HD uint32_t kid_mmer_hash2(uint32_t f, uint32_t r)
+{
+    uint32_t h = f < r ? f : r;
+    h *= 0x9E3779B1u;
+    h ^= h >> 15;
+    return h;
+}
+
 // minimizer of a whole k-mer given as its 2k-bit forward key (brute force: table build, unit lookups)
 KID_HD uint32_t kid_minimizer_of_key(uint64_t keyF, int k)
 {

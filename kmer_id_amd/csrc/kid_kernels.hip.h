@@ -18,7 +18,21 @@
 
 #define KID_WAVE 64
 #define KID_SEG_KMERS 960  // k-mers per read segment: 960 + 30 bases + 15 alignment slack <= 64 chunks of 16 B
-#define KID_WAVE_LDS_WORDS 100 // 66 packed-base words + 34 invalid-mask words per wave
+#define KID_WAVE_LDS_WORDS 104 // per wave, general loops: 66 packed-base words + 34 invalid-mask words + 4 counters
+// pair kernel: + a second strip (100), the per-read results of 64 reads (64), a queue of hit cells (128)
+#define KID_PAIR_LDS_WORDS 396
+#define KID_SEENQ_WORDS 128
+#if defined(KID_ABLATE) && KID_ABLATE >= 2
+#define KID_ABLATE_NOMIN 1
+#else
+#define KID_ABLATE_NOMIN 0
+#endif
+#ifndef KID_PAIRS
+#define KID_PAIRS 1 // the hand-pipelined pair loop for batches of single-group reads
+#endif
+#ifndef KID_CLASSIFY_OCC
+#define KID_CLASSIFY_OCC 8 // waves per SIMD the register allocator must leave room for
+#endif
 
 typedef uint32_t kid_u4 __attribute__((ext_vector_type(4)));
 
@@ -31,6 +45,20 @@ typedef uint32_t kid_u4 __attribute__((ext_vector_type(4)));
 #ifndef KID_PAIR
 #define KID_PAIR 0
 #endif
+// Fire-and-forget global writes of the classify kernel (per-read result, seen-bitmap bits).  Issued
+// from inline assembly so that the compiler's waitcnt insertion does not know them: on gfx9 a pending
+// store or no-return atomic shares vmcnt with the loads and makes the next wait a full vmcnt(0) drain,
+// i.e. every read would sit out the write acknowledgement of the one before.  Nothing in the kernel
+// reads these locations back; they complete before the kernel does.
+__device__ __forceinline__ void kid_store_u32_nowait(uint32_t *p, uint32_t v)
+{
+    asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void kid_atomic_or_nowait(uint32_t *p, uint32_t v)
+{
+    asm volatile("global_atomic_or %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ uint4 kid_load_cell(const uint4 *table, uint32_t idx)
 {
 #if KID_NT
@@ -87,6 +115,16 @@ struct KidSampleDev {
     unsigned long long *gcount;
     uint32_t *seen;
     unsigned long long *stats; // [0] reads [1] lookups [2] probes [3] hits [4] argument errors
+};
+
+// What only rare paths of the classify kernel need (hit cells, the flush at the end): kept in device
+// memory and loaded where used, so it does not occupy scalar registers across the hot loop.
+struct KidRareArgs {
+    unsigned long long *gcount;
+    unsigned long long *stats;
+    uint32_t line_mask;
+    uint32_t pad;
+    unsigned long long batch_max; // (batch sequence number << 32) | largest n_kmers of the batch: kid_prepare_kernel
 };
 
 // ------------------------------------------------------------------ hash lookup
@@ -246,9 +284,9 @@ __device__ __forceinline__ void kid_pack16(const uint4 v, const uint32_t u_is_t,
 
 // ------------------------------------------------------------------ batch preparation
 // [start, stop] -> descriptor; the range checks the reference leaves to string::at() happen here
-__global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, unsigned long long *stats)
+__global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, unsigned long long *stats, KidRareArgs *rare, uint32_t seq)
 {
-    uint32_t bad = 0;
+    uint32_t bad = 0, mx = 0;
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < b.n; r += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t off;
         int64_t rl;
@@ -268,7 +306,12 @@ __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, u
         d.n_kmers = (int32_t)(nk > 0x7FFFFFFF ? 0x7FFFFFFF : nk);
         d.pad = 0;
         desc[r] = d;
+        if (d.n_kmers > 0 && (uint32_t)d.n_kmers > mx) mx = (uint32_t)d.n_kmers;
     }
+    // largest read of the batch, tagged with the batch number so that the word never needs a reset
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)mx, o); mx = y > mx ? y : mx; }
+    if ((threadIdx.x & 63u) == 0) atomicMax(&rare->batch_max, ((unsigned long long)seq << 32) | mx);
     if (bad) atomicAdd(&stats[4], (unsigned long long)bad);
 }
 
@@ -298,11 +341,36 @@ __global__ void kid_pack_kernel(const uint8_t *bases, uint64_t nchunks, uint32_t
 //      associative: newkmer_10nx.cpp:588-595) on wave-uniform registers;
 //   5. hit cells are marked in the sample's seen-bitmap (ucount, :596-603).
 // gcount is accumulated in an LDS histogram per workgroup and flushed once.
-template <int U, bool ROWS, bool HIST, bool MINLOC, int KFIX>
-__global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db, const KidPacked b, const KidSampleDev s,
+//
+// A wave is latency-bound (every read is a chain of dependent round trips: LDS strip, table header,
+// hit cell, ancestor row), so short reads -- one group of <= U*64 windows, the Illumina case -- are
+// taken two at a time: steps 1-3a (up to the header loads) of read A, the same of read B, then
+// steps 3b-5 of A and of B, which doubles the table loads a wave keeps in flight.
+template <int U>
+struct KidGroup {      // a group of U*64 windows between its two halves
+    uint64_t key[U];
+    uint32_t hlo[U];   // reference geometry: first cell of the probe sequence; minloc: the table line
+    uint4 hd[U];       // minloc: header of that line (in flight)
+    uint32_t fpp;      // minloc: the 16-bit key fingerprints of the U lookups, packed
+    bool act[U];
+};
+
+// Two instantiations per configuration share this body: PAIRK = true holds only the hand-pipelined
+// pair loop (batches of single-group reads), PAIRK = false the general loops; both are launched for
+// every batch and the one the batch is not for returns at once (kid_prepare_kernel left the longest
+// read of the batch in rare->batch_max).  Separate kernels, because each loop wants all 64 vector
+// registers of an 8-waves-per-SIMD kernel for itself.
+template <int U, bool ROWS, bool HIST, bool MINLOC, int KFIX, bool PAIRK>
+__global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(const KidDevDb db, const KidPacked b, const KidSampleDev s,
                                                             const uint32_t hist_words,
-                                                            const KidReadDesc *__restrict__ const descs)
+                                                            const KidReadDesc *__restrict__ const descs,
+                                                            const KidRareArgs *__restrict__ const rare)
 {
+    static_assert(!PAIRK || (MINLOC && U == 2), "the pair loop exists for the minimizer-localised table, two windows per lane");
+    if (MINLOC && KID_PAIRS) { // wave-uniform, before anything else
+        const bool pairs = (uint32_t)rare->batch_max <= (uint32_t)(U * 64);
+        if (pairs != PAIRK) return;
+    }
     // (descs == b.desc, passed once more as a restrict-qualified argument: the wave-uniform
     //  descriptor loads then become scalar loads, which stay in flight until first use)
     extern __shared__ uint32_t kid_smem[];
@@ -310,9 +378,7 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform
     const uint32_t wpb = blockDim.x >> 6;
     uint32_t *hist = kid_smem;
-    uint32_t *W = kid_smem + hist_words + wib * KID_WAVE_LDS_WORDS; // 66 words
-    uint32_t *IM = W + 66;                                          // 34 words
-    uint16_t *IM16 = reinterpret_cast<uint16_t *>(IM);
+    uint32_t *WA = kid_smem + hist_words + wib * (PAIRK ? KID_PAIR_LDS_WORDS : KID_WAVE_LDS_WORDS); // strip: 66 packed words + 34 mask words
 
     if (HIST) {
         for (uint32_t i = threadIdx.x; i < hist_words; i += blockDim.x) hist[i] = 0;
@@ -322,294 +388,583 @@ __global__ __launch_bounds__(512, 8) void kid_classify_kernel(const KidDevDb db,
     const int k = KFIX ? KFIX : db.k; // KFIX = 30: the reference's KSIZE folded into the shifts and masks
     const uint32_t win = (uint32_t)kid_min_window(k); // m-mers per k-mer window: 15 or 16
     const int mlen = kid_min_mlen(k);
+    // lane classes of the sliding minimum.  With q = lane mod 16 the window of a lane leaves its 16-lane
+    // row iff q + win > 16: then it is min(S[p], P[p+win-1]); inside one row it is the prefix P[p+win-1]
+    // alone (q = 0) or the suffix alone (q = 1, win = 15)
+    const uint32_t bp_src = ((lane + win - 1u) & 63u) << 2; // ds_bpermute address of lane + win - 1
+    const bool p_same = lane + win - 1u < 64u;              // that lane is in the same tile
+    const bool p_cross = (lane & 15u) + win > 16u, p_q0 = (lane & 15u) == 0u;
     const uint64_t gw = (uint64_t)blockIdx.x * wpb + wib;
     const uint64_t nw = (uint64_t)gridDim.x * wpb;
-    uint32_t n_lookups = 0, n_probes = 0;  // per lane, per workgroup-lifetime: far below 2^32
-    uint32_t n_hits = 0, n_reads = 0;      // wave-uniform
+    // Counters for kid_sample_stats.  Wave-uniform state that only rare paths touch is kept out of
+    // scalar registers (80 per wave at this occupancy, and the hot loop wants them all): lookups and
+    // hits accumulate in the wave's LDS words, the msca row of the running result in lanes 0-3 of a
+    // vector register, the probes beyond the first in a per-lane counter.
+    uint32_t *const WC = WA + 100; // [0..1] lookups (64 bits), [2] hits, [3] probes beyond the first of a lookup
+    unsigned long long *const WL = reinterpret_cast<unsigned long long *>(WC);
+    if (lane < 4) WC[lane] = 0;
     uint32_t pend_t = 0, pend_n = 0;       // !HIST: run-length buffer in front of the global gcount atomics
+    // Pair kernel: global writes are batched.  A pending store or atomic shares vmcnt with the loads, and
+    // every vmcnt(0) the compiler places (hit cells, ancestor rows) would sit out its acknowledgement;
+    // so the per-read results wait in RB (one scattered store per 64 reads) and the hit cells in SQ
+    // (64 atomics at a time).
+    uint32_t *const RB = WA + 204, *const SQ = WA + 268;
+    uint32_t sq_n = 0; // wave-uniform fill of SQ
+    auto flush_seen = [&](const uint32_t n) { // the first n (<= 64) entries of SQ
+        if (lane < n) {
+            const uint32_t slot = SQ[lane];
+            kid_atomic_or_nowait(&s.seen[slot >> 5], 1u << (slot & 31u));
+        }
+    };
+#ifdef KID_ABLATE
+    uint32_t sink = 0;
+#endif
 
-    // ---- everything that happens to one read, given its descriptor and its first packed segment
-    // `prefetch` issues the loads for the reads behind this one; it is called right after this read's
-    // header loads went out (not before the loops: the compiler drains vmcnt in front of a loop)
-    auto process_read = [&](const uint64_t r, const uint64_t first, const int64_t nk, const uint32_t st_codes,
-                            const uint32_t st_inv, auto &&prefetch) {
-        bool prefetched = false;
-            uint32_t final_t = 0;
-            uint4 frow = make_uint4(0, 0, 0, 0);
+#ifdef KID_PROFILE // development aid: cycles of a wave per phase of the sequential read loop
+    unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
+#define KID_TICK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[i] += t_ - prof_t; prof_t = t_; } while (0)
+#define KID_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define KID_TICK(i) do { } while (0)
+#define KID_DRAIN() do { } while (0)
+#endif
+    // ---- 1. stage one packed segment in a strip; returns "no base of it resets a window" (wave-uniform)
+    auto stage = [&](uint32_t *W, const uint32_t codes, const uint32_t inv) -> bool {
+        uint32_t *IM = W + 66;
+        W[lane] = codes;
+        reinterpret_cast<uint16_t *>(IM)[lane] = (uint16_t)inv;
+        if (lane < 2) { W[64 + lane] = 0; IM[32 + lane] = 0; }
+        const bool clean = (__ballot(inv != 0) == 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        return clean;
+    };
 
-            for (int64_t seg = 0; seg < nk; seg += KID_SEG_KMERS) {
-                const uint32_t segk = (uint32_t)((nk - seg) < KID_SEG_KMERS ? (nk - seg) : KID_SEG_KMERS);
-                const uint64_t b0 = first + (uint64_t)seg; // first base of the segment
-                const uint32_t nb = segk + (uint32_t)k - 1;
-                const uint64_t c0 = b0 >> 4;
-                const uint32_t sh = (uint32_t)(b0 & 15ull);
-                const uint32_t nchunks = (sh + nb + 15u) >> 4; // <= 64
-
-                // ---- 1. stage the packed segment
-                bool seg_clean;
-                {
-                    uint32_t codes = st_codes, inv = st_inv;
-                    if (seg != 0) { // long reads: later segments are fetched on the spot
-                        codes = 0; inv = 0;
-                        if (lane < nchunks) {
-                            codes = b.codes[c0 + lane];
-                            inv = b.inval[c0 + lane];
-                        }
-                    }
-                    W[lane] = codes;
-                    IM16[lane] = (uint16_t)inv;
-                    if (lane < 2) { W[64 + lane] = 0; IM[32 + lane] = 0; }
-                    seg_clean = (__ballot(inv != 0) == 0); // wave-uniform: no base of this segment resets a window
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-                // ---- 2..5 per group of U*64 windows
-                for (uint32_t t0 = 0; t0 < segk; t0 += U * 64u) {
-                    uint64_t key[U];
-                    uint32_t hlo[U]; // reference geometry: first cell of the probe sequence; minloc: the minimizer
-                    bool act[U];
-                    uint32_t P[U + 1], S[U]; // minloc: row prefix / suffix minima of the hashed m-mers
-                    const uint32_t pmax = sh + nb - (uint32_t)mlen; // last m-mer start inside the segment
-    #pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const uint32_t i = t0 + (uint32_t)u * 64u + lane;
-                        // one window extraction serves the k-mer AND the m-mer that starts at the same base;
-                        // lanes past the last k-mer still hash their m-mer (the windows of earlier lanes reach
-                        // 14 positions ahead), clamped to the last one that lies inside the segment
-                        uint32_t p = sh + i;
-                        p = MINLOC ? (p < pmax ? p : pmax) : sh + (i < segk ? i : 0u);
-                        const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
-                        const uint64_t A = ((uint64_t)W[w0] << 32) | W[w0 + 1];
-                        const uint64_t B = W[w0 + 2];
-                        const uint64_t x = (A << o2) | ((B << o2) >> 32);
-                        const uint64_t keyF = x >> (64 - 2 * k);
-                        bool valid = (i < segk);
-                        if (!seg_clean) { // rare: some base of the segment is not ACGTacgt
-                            const uint64_t im = (((uint64_t)IM[(p >> 5) + 1] << 32) | IM[p >> 5]) >> (p & 31u);
-                            valid = valid && ((im & ((1ull << k) - 1ull)) == 0);
-                        }
-                        key[u] = kid_canonical(keyF, k);
-                        if (!MINLOC) hlo[u] = (uint32_t)kid_fmix64(key[u]) & db.slot_mask;
-                        act[u] = valid;
-                        n_lookups += valid ? 1u : 0u;
-                        if (MINLOC) {
-                            const uint32_t h = kid_mmer_hash((uint32_t)(x >> (64 - 2 * mlen)), mlen);
-                            P[u] = kid_row_prefix_min(h);
-                            S[u] = kid_row_suffix_min(h);
-                        }
-                    }
-                    if (MINLOC) {
-                        { // the win-1 m-mers behind the last k-mer of the group
-                            uint32_t p = sh + t0 + (uint32_t)U * 64u + lane;
-                            p = p < pmax ? p : pmax;
-                            const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
-                            const uint64_t A = ((uint64_t)W[w0] << 32) | W[w0 + 1];
-                            P[U] = kid_row_prefix_min(kid_mmer_hash((uint32_t)((A << o2) >> (64 - 2 * mlen)), mlen));
-                        }
-                        // ... and their minimum over every window a[p..p+win-1].  With q = p mod 16: the window
-                        // leaves its 16-lane row iff q + win > 16, then it is min(S[p], P[p+win-1]); inside
-                        // one row it is exactly the prefix P[p+win-1] (q = 0) or the suffix S[p] (win = 15, q = 1)
-                        const uint32_t src = (lane + win - 1u) & 63u;
-                        const uint32_t q16 = lane & 15u;
-                        uint32_t nxt = (uint32_t)__shfl((int)P[0], (int)src);
-    #pragma unroll
-                        for (int u = 0; u < U; u++) {
-                            const uint32_t same = nxt;
-                            nxt = (uint32_t)__shfl((int)P[u + 1], (int)src);
-                            const uint32_t pn = (lane + win - 1u < 64u) ? same : nxt;
-                            const uint32_t both = S[u] < pn ? S[u] : pn;
-                            hlo[u] = (q16 + win > 16u) ? both : (q16 == 0u ? pn : S[u]);
-                        }
-                    }
-                    uint32_t tgt[U], slot[U], step[U];
-    #pragma unroll
-                    for (int u = 0; u < U; u++) { tgt[u] = 0; slot[u] = 0; step[u] = 0; }
-                    if (MINLOC) {
-                        // one 16-byte header per lookup settles every absent key; lanes that share a
-                        // minimizer read the same header (one sector for all of them)
-                        uint4 hd[U];
-                        uint32_t mm[U], fp[U], line[U];
-    #pragma unroll
-                        for (int u = 0; u < U; u++) {
-                            line[u] = kid_minloc_line(hlo[u], db.line_shift);
-                            hd[u] = make_uint4(0, 0, 0, 0);
-                            if (act[u]) hd[u] = kid_load_cell(db.table, line[u] * KID_LINE_CELLS);
-                        }
-                        if (!prefetched) { prefetch(); prefetched = true; }
-                        bool more = false;
-    #pragma unroll
-                        for (int u = 0; u < U; u++) {
-                            fp[u] = kid_key_fp(key[u]);
-                            step[u] = act[u] ? 1u : 0u;
-                            mm[u] = (act[u] && (kid_hdr_any(hd[u], fp[u]) || (hd[u].w >> 16) >= KID_HDR_FULL)) ? 1u : 0u;
-                            more |= mm[u] != 0;
-                        }
-                        if (more) { // ~1 % of the lanes: fingerprint matches (hits) and chained lines
-    #pragma unroll
-                            for (int u = 0; u < U; u++) {
-                                bool go = mm[u] != 0;
-                                uint4 h = hd[u];
-                                uint32_t m = go ? kid_hdr_cand(h, fp[u]) : 0u, ln = line[u];
-                                while (go) {
-                                    if (m) {
-                                        const uint32_t j = kid_cand_entry((uint32_t)__builtin_ctz(m));
-                                        m &= m - 1;
-                                        const uint32_t idx = ln * KID_LINE_CELLS + 1u + j;
-                                        const uint4 c = kid_load_cell(db.table, idx);
-                                        step[u]++;
-                                        if (c.z != 0 && c.x == (uint32_t)key[u] && c.y == (uint32_t)(key[u] >> 32)) { tgt[u] = c.z; slot[u] = idx; go = false; }
-                                    } else if ((h.w >> 16) >= KID_HDR_FULL) {
-                                        ln = (ln + 1u) & db.line_mask;
-                                        h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
-                                        step[u]++;
-                                        m = kid_hdr_cand(h, fp[u]);
-                                    } else go = false;
-                                }
-                            }
-                        }
-                    } else {
-                        uint64_t rp[U];
-    #pragma unroll
-                        for (int u = 0; u < U; u++) rp[u] = 0;
-                        bool any = false;
-    #pragma unroll
-                        for (int u = 0; u < U; u++) any |= act[u];
-                        while (any) {
-                            uint4 c[U];
-                            uint32_t idx[U];
-    #pragma unroll
-                            for (int u = 0; u < U; u++) {
-                                idx[u] = (hlo[u] + (uint32_t)rp[u]) & db.slot_mask;
-                                c[u] = make_uint4(0, 0, 0, 0);
-                                if (act[u]) c[u] = kid_load_cell(db.table, idx[u]);
-                            }
-                            any = false;
-    #pragma unroll
-                            for (int u = 0; u < U; u++) {
-                                if (act[u]) {
-                                    step[u]++;
-                                    rp[u] += step[u];
-                                    if (c[u].z == 0) act[u] = false;
-                                    else if (c[u].x == (uint32_t)key[u] && c[u].y == (uint32_t)(key[u] >> 32)) {
-                                        tgt[u] = c[u].z; slot[u] = idx[u]; act[u] = false;
-                                    } else if (!(rp[u] < db.nslots) || (db.max_probes != 0 && step[u] >= db.max_probes)) act[u] = false;
-                                }
-                                any |= act[u];
-                            }
-                        }
-                    }
-                    uint4 row[U];
-    #pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        n_probes += step[u];
-                        row[u] = make_uint4(0, 0, 0, 0);
-                        if (tgt[u] > 0) {
-                            if (ROWS) row[u] = db.rows[tgt[u]];
-                            if (tgt[u] > 1) atomicOr(&s.seen[slot[u] >> 5], 1u << (slot[u] & 31u));
-                        }
-                    }
-                    // ---- 3. ordered fold over the hits (wave-uniform)
-    #pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        uint64_t m = __ballot(tgt[u] > 0);
-                        n_hits += (uint32_t)__popcll(m);
-                        while (m) {
-                            const int j = __builtin_ctzll(m);
-                            m &= m - 1;
-                            const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)tgt[u], j);
-                            if (x == final_t) continue; // msca(x,x) = x
-                            uint4 rx = make_uint4(0, 0, 0, 0);
-                            if (ROWS) {
-                                rx.x = (uint32_t)__builtin_amdgcn_readlane((int)row[u].x, j);
-                                rx.y = (uint32_t)__builtin_amdgcn_readlane((int)row[u].y, j);
-                                rx.z = (uint32_t)__builtin_amdgcn_readlane((int)row[u].z, j);
-                                rx.w = (uint32_t)__builtin_amdgcn_readlane((int)row[u].w, j);
-                            }
-                            if (final_t == 0) { final_t = x; frow = rx; continue; } // :592-595
-                            if (ROWS) {
-                                uint4 ro;
-                                final_t = kid_msca_rows(x, rx, final_t, frow, ro); // :588-591
-                                frow = ro;
-                            } else {
-                                final_t = kid_msca_climb(db, x, final_t);
-                            }
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier(); // strip is rewritten by the next segment / read
+    // ---- 2, 3a. windows [t0, t0 + U*64) of the staged segment: keys, table line, header loads issued
+    auto group_front = [&](const uint32_t *W, const uint32_t sh, const uint32_t nb, const uint32_t segk, const uint32_t t0,
+                           const bool seg_clean, KidGroup<U> &g, uint32_t &n_bad, const bool issue_loads = true) {
+        const uint32_t *IM = W + 66;
+        uint32_t P[U + 1], S[U]; // minloc: row prefix / suffix minima of the hashed m-mers
+        const uint32_t pmax = sh + nb - (uint32_t)mlen; // last m-mer start inside the segment
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t i = t0 + (uint32_t)u * 64u + lane;
+            // one window extraction serves the k-mer AND the m-mer that starts at the same base;
+            // lanes past the last k-mer still hash their m-mer (the windows of earlier lanes reach
+            // 14 positions ahead), clamped to the last one that lies inside the segment
+            uint32_t p = sh + i;
+            p = MINLOC ? (p < pmax ? p : pmax) : sh + (i < segk ? i : 0u);
+            const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
+            const uint64_t A = ((uint64_t)W[w0] << 32) | W[w0 + 1];
+            const uint64_t B = W[w0 + 2];
+            const uint64_t x = (A << o2) | ((B << o2) >> 32);
+            const uint64_t keyF = x >> (64 - 2 * k);
+            // one reversal of the 32-base window serves both reverse complements: base j of the window
+            // lands in bits [2j+1, 2j], so the low 2k bits are the k-mer's and the low 2m bits the m-mer's
+            const uint64_t nrv = ~kid_rev2(x);
+            const uint64_t keyR = nrv & (~0ull >> (64 - 2 * k));
+            bool valid = (i < segk);
+            if (!seg_clean) { // rare: some base of the segment is not ACGTacgt
+                const uint64_t im = (((uint64_t)IM[(p >> 5) + 1] << 32) | IM[p >> 5]) >> (p & 31u);
+                const bool ok = ((im & ((1ull << k) - 1ull)) == 0);
+                n_bad += (uint32_t)__popcll(__ballot(valid && !ok));
+                valid = valid && ok;
             }
+            g.key[u] = keyF < keyR ? keyF : keyR; // newkmer_10nx.cpp:528
+            if (!MINLOC) g.hlo[u] = (uint32_t)kid_fmix64(g.key[u]) & db.slot_mask;
+            g.act[u] = valid;
+            if (MINLOC && !KID_ABLATE_NOMIN) {
+                const uint32_t h = kid_mmer_hash2((uint32_t)(x >> (64 - 2 * mlen)), (uint32_t)nrv & (0xFFFFFFFFu >> (32 - 2 * mlen)));
+                P[u] = kid_row_prefix_min(h);
+                S[u] = kid_row_suffix_min(h);
+            }
+        }
+#if defined(KID_ABLATE) && KID_ABLATE >= 2
+        if (false) {
+#else
+        if (MINLOC) {
+#endif
+            g.fpp = 0;
+#pragma unroll
+            for (int u = 0; u < U; u++) g.fpp |= kid_key_fp(g.key[u]) << (16 * u);
+            { // the win-1 m-mers behind the last k-mer of the group
+                uint32_t p = sh + t0 + (uint32_t)U * 64u + lane;
+                p = p < pmax ? p : pmax;
+                const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
+                const uint64_t A = ((uint64_t)W[w0] << 32) | W[w0 + 1];
+                P[U] = kid_row_prefix_min(kid_mmer_hash((uint32_t)((A << o2) >> (64 - 2 * mlen)), mlen));
+            }
+            // ... and their minimum over every window a[p..p+win-1].  With q = p mod 16: the window
+            // leaves its 16-lane row iff q + win > 16, then it is min(S[p], P[p+win-1]); inside
+            // one row it is exactly the prefix P[p+win-1] (q = 0) or the suffix S[p] (win = 15, q = 1)
+            uint32_t nxt = (uint32_t)__builtin_amdgcn_ds_bpermute((int)bp_src, (int)P[0]);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t same = nxt;
+                nxt = (uint32_t)__builtin_amdgcn_ds_bpermute((int)bp_src, (int)P[u + 1]);
+                const uint32_t pn = p_same ? same : nxt;
+                const uint32_t both = S[u] < pn ? S[u] : pn;
+                const uint32_t mz = p_cross ? both : (p_q0 ? pn : S[u]);
+                // one 16-byte header per lookup settles every absent key; lanes that share a
+                // minimizer read the same header (one sector for all of them)
+                g.hlo[u] = kid_minloc_line(mz, db.line_shift);
+                g.hd[u] = make_uint4(0, 0, 0, 0);
+                if (issue_loads && g.act[u]) g.hd[u] = kid_load_cell(db.table, g.hlo[u] * KID_LINE_CELLS);
+            }
+        }
+    };
 
-            n_reads++;
-            if (HIST) {
-                if (lane == 0) atomicAdd(&hist[final_t], 1u);
-            } else if (final_t == pend_t) {
+    // ---- 3b, 4, 5. the rest of the probe sequences, seen-bitmap, ordered fold into final_t (vfrow:
+    // the ancestor row of final_t, in lanes 0-3)
+    auto group_back = [&](KidGroup<U> &g, uint32_t &final_t, uint32_t &vfrow) {
+        uint32_t tgt[U], slot[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { tgt[u] = 0; slot[u] = 0; }
+        if (MINLOC) {
+            uint32_t mm[U], fp[U];
+            bool more = false;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                fp[u] = (g.fpp >> (16 * u)) & 0xFFFFu;
+                mm[u] = (g.act[u] && (kid_hdr_any(g.hd[u], fp[u]) || (g.hd[u].w >> 16) >= KID_HDR_FULL)) ? 1u : 0u;
+                more |= mm[u] != 0;
+            }
+            if (__ballot(more) == 0) return; // (wave-uniform) ~99 % of the lanes are settled by their header
+#ifdef KID_ABLATE_NOHIT // timing experiment only: pretend no fingerprint ever matches
+            if (PAIRK) return;
+#endif
+            // fingerprint matches (almost always the key itself): the first candidate cell of every
+            // pending lookup is requested at once -- one round trip for the whole group.  From here on a
+            // header is only its candidate set and its "line continues" flag.
+            uint32_t m[U], idx[U];
+            bool full[U];
+            uint4 c[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                m[u] = mm[u] ? kid_hdr_cand(g.hd[u], fp[u]) : 0u;
+                full[u] = mm[u] && (g.hd[u].w >> 16) >= KID_HDR_FULL;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                idx[u] = 0;
+                c[u] = make_uint4(0, 0, 0, 0);
+                if (m[u]) {
+                    idx[u] = g.hlo[u] * KID_LINE_CELLS + 1u + kid_cand_entry((uint32_t)__builtin_ctz(m[u]));
+                    m[u] &= m[u] - 1;
+                    c[u] = kid_load_cell(db.table, idx[u]);
+                    atomicAdd(&WC[3], 1u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                bool go = mm[u] != 0;
+                if (idx[u] && c[u].z != 0 && c[u].x == (uint32_t)g.key[u] && c[u].y == (uint32_t)(g.key[u] >> 32)) {
+                    tgt[u] = c[u].z; slot[u] = idx[u]; go = false;
+                }
+                // leftovers (a second candidate: 1e-4 of the lookups; a chained line: 1e-5)
+                uint32_t ln = g.hlo[u], mu = m[u];
+                bool fu = full[u];
+                while (go) {
+                    if (mu) {
+                        const uint32_t j = kid_cand_entry((uint32_t)__builtin_ctz(mu));
+                        mu &= mu - 1;
+                        const uint32_t ix = ln * KID_LINE_CELLS + 1u + j;
+                        const uint4 cc = kid_load_cell(db.table, ix);
+                        atomicAdd(&WC[3], 1u);
+                        if (cc.z != 0 && cc.x == (uint32_t)g.key[u] && cc.y == (uint32_t)(g.key[u] >> 32)) { tgt[u] = cc.z; slot[u] = ix; go = false; }
+                    } else if (fu) {
+                        ln = (ln + 1u) & rare->line_mask;
+                        const uint4 h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
+                        atomicAdd(&WC[3], 1u);
+                        mu = kid_hdr_cand(h, fp[u]);
+                        fu = (h.w >> 16) >= KID_HDR_FULL;
+                    } else go = false;
+                }
+            }
+        } else {
+            uint64_t rp[U];
+            uint32_t step[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) { rp[u] = 0; step[u] = 0; }
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < U; u++) any |= g.act[u];
+            while (any) {
+                uint4 c[U];
+                uint32_t idx[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    idx[u] = (g.hlo[u] + (uint32_t)rp[u]) & db.slot_mask;
+                    c[u] = make_uint4(0, 0, 0, 0);
+                    if (g.act[u]) c[u] = kid_load_cell(db.table, idx[u]);
+                }
+                any = false;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (g.act[u]) {
+                        step[u]++;
+                        rp[u] += step[u];
+                        if (step[u] > 1) atomicAdd(&WC[3], 1u);
+                        if (c[u].z == 0) g.act[u] = false;
+                        else if (c[u].x == (uint32_t)g.key[u] && c[u].y == (uint32_t)(g.key[u] >> 32)) {
+                            tgt[u] = c[u].z; slot[u] = idx[u]; g.act[u] = false;
+                        } else if (!(rp[u] < db.nslots) || (db.max_probes != 0 && step[u] >= db.max_probes)) g.act[u] = false;
+                    }
+                    any |= g.act[u];
+                }
+            }
+        }
+        uint4 row[U];
+        uint64_t hitm[U];
+        uint32_t nh = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            row[u] = make_uint4(0, 0, 0, 0);
+            if (tgt[u] > 0) {
+                if (ROWS) row[u] = db.rows[tgt[u]];
+                if (!PAIRK && tgt[u] > 1) kid_atomic_or_nowait(&s.seen[slot[u] >> 5], 1u << (slot[u] & 31u));
+            }
+            if (PAIRK) { // append the hit cells to SQ (wave-uniform bookkeeping), writing out 64 at a time
+                const uint64_t qm = __ballot(tgt[u] > 1);
+                const uint32_t qc = (uint32_t)__popcll(qm);
+                if (qc) {
+                    if (sq_n + qc > KID_SEENQ_WORDS) { // cannot happen with sq_n < 64 and qc <= 64; kept as a guard
+                        flush_seen(sq_n < 64u ? sq_n : 64u);
+                        sq_n = 0;
+                    }
+                    if (tgt[u] > 1) SQ[sq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u))] = slot[u];
+                    sq_n += qc;
+                    if (sq_n >= 64u) {
+                        flush_seen(64u);
+                        const uint32_t rest = sq_n - 64u;    // < 64: move the tail to the front
+                        uint32_t t = 0;
+                        if (lane < rest) t = SQ[64u + lane];
+                        if (lane < rest) SQ[lane] = t;
+                        sq_n = rest;
+                    }
+                }
+            }
+            hitm[u] = __ballot(tgt[u] > 0);
+            nh += (uint32_t)__popcll(hitm[u]);
+        }
+        if (nh == 0) return;
+        if (lane == 0) atomicAdd(&WC[2], nh);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            uint64_t m = hitm[u];
+            while (m) {
+                const int j = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)tgt[u], j);
+                if (x == final_t) continue; // msca(x,x) = x
+                uint4 rx = make_uint4(0, 0, 0, 0);
+                if (ROWS) {
+                    rx.x = (uint32_t)__builtin_amdgcn_readlane((int)row[u].x, j);
+                    rx.y = (uint32_t)__builtin_amdgcn_readlane((int)row[u].y, j);
+                    rx.z = (uint32_t)__builtin_amdgcn_readlane((int)row[u].z, j);
+                    rx.w = (uint32_t)__builtin_amdgcn_readlane((int)row[u].w, j);
+                }
+                if (final_t != 0) { // :588-591
+                    if (ROWS) {
+                        uint4 fr, ro;
+                        fr.x = (uint32_t)__builtin_amdgcn_readlane((int)vfrow, 0);
+                        fr.y = (uint32_t)__builtin_amdgcn_readlane((int)vfrow, 1);
+                        fr.z = (uint32_t)__builtin_amdgcn_readlane((int)vfrow, 2);
+                        fr.w = (uint32_t)__builtin_amdgcn_readlane((int)vfrow, 3);
+                        final_t = kid_msca_rows(x, rx, final_t, fr, ro);
+                        rx = ro;
+                    } else {
+                        final_t = kid_msca_climb(db, x, final_t);
+                    }
+                } else {
+                    final_t = x; // :592-595
+                }
+                if (ROWS)
+                    vfrow = lane == 0 ? rx.x : lane == 1 ? rx.y : lane == 2 ? rx.z : lane == 3 ? rx.w : vfrow;
+            }
+        }
+    };
+
+    // ---- gcount[final]++ (:605) and the per-read output
+    auto finish_read = [&](const uint64_t r, const uint32_t final_t, const uint32_t n_valid) {
+        if (HIST) {
+            if (lane == 0) { atomicAdd(&hist[final_t], 1u); atomicAdd(WL, (unsigned long long)n_valid); }
+        } else {
+            if (lane == 0) atomicAdd(WL, (unsigned long long)n_valid);
+            if (final_t == pend_t) {
                 pend_n++;
             } else {
-                if (pend_n && lane == 0) atomicAdd(&s.gcount[pend_t], (unsigned long long)pend_n);
+                if (pend_n && lane == 0) atomicAdd(&rare->gcount[pend_t], (unsigned long long)pend_n);
                 pend_t = final_t;
                 pend_n = 1;
             }
-            if (lane == 0 && b.out_final) b.out_final[r] = final_t;
-            if (!prefetched) prefetch();
+        }
+        if (!PAIRK && lane == 0 && b.out_final) kid_store_u32_nowait(&b.out_final[r], final_t);
     };
 
-    // Software pipeline over the reads of this wave, unrolled by two with two named register sets
-    // (A, B) so that nothing is copied between stages: the descriptor of a read is requested two
-    // reads ahead and its first packed segment one read ahead, and the waits the compiler places in
-    // front of their first use land behind a whole read's worth of work (a wave is latency-bound:
-    // every read is a chain of dependent memory round trips).
-    auto fetch_desc = [&](uint64_t r, KidReadDesc &d) {
+    // ---- a whole read of any length on its own, given its descriptor and its first packed segment.
+    // `prefetch` issues the loads for the reads behind this one; it is called right after this read's
+    // first header loads went out (not before the loops: the compiler drains vmcnt in front of a loop)
+    auto process_read = [&](const uint64_t r, const uint64_t first, const int64_t nk, const uint32_t st_codes,
+                            const uint32_t st_inv, auto &&prefetch) {
+        bool prefetched = false;
+        uint32_t final_t = 0;
+        uint32_t vfrow = 0, n_bad = 0;
+        for (int64_t seg = 0; seg < nk; seg += KID_SEG_KMERS) {
+            const uint32_t segk = (uint32_t)((nk - seg) < KID_SEG_KMERS ? (nk - seg) : KID_SEG_KMERS);
+            const uint64_t b0 = first + (uint64_t)seg; // first base of the segment
+            const uint32_t nb = segk + (uint32_t)k - 1;
+            const uint64_t c0 = b0 >> 4;
+            const uint32_t sh = (uint32_t)(b0 & 15ull);
+            const uint32_t nchunks = (sh + nb + 15u) >> 4; // <= 64
+            uint32_t codes = st_codes, inv = st_inv;
+            if (seg != 0) { // long reads: later segments are fetched on the spot
+                codes = 0; inv = 0;
+                if (lane < nchunks) {
+                    codes = b.codes[c0 + lane];
+                    inv = b.inval[c0 + lane];
+                }
+            }
+            const bool seg_clean = stage(WA, codes, inv);
+            for (uint32_t t0 = 0; t0 < segk; t0 += U * 64u) {
+                KidGroup<U> g;
+                group_front(WA, sh, nb, segk, t0, seg_clean, g, n_bad);
+                if (!prefetched) { prefetch(); prefetched = true; }
+                group_back(g, final_t, vfrow);
+            }
+            __builtin_amdgcn_wave_barrier(); // strip is rewritten by the next segment / read
+        }
+        finish_read(r, final_t, (nk > 0 ? (uint32_t)nk : 0u) - n_bad);
+        if (!prefetched) prefetch();
+    };
+
+    auto fetch_desc = [&](uint32_t r, KidReadDesc &d) {
         d.first_base = 0; d.n_kmers = 0; d.pad = 0;
-        if (r < b.n) d = descs[r];
+#ifdef KID_FIXED_HACK // experiment only: descriptors of fixed-length reads computed, not loaded
+        if (r < (uint32_t)b.n) { d.first_base = (uint64_t)r * KID_FIXED_HACK; d.n_kmers = KID_FIXED_HACK - 29; }
+#else
+        if (r < (uint32_t)b.n) d = descs[r];
+#endif
     };
     auto fetch_words = [&](const KidReadDesc &d, uint32_t &codes, uint32_t &inv) {
         // unconditional (the scratch arrays are padded by 64 entries): a fixed number of loads keeps the
         // compiler's vmcnt bookkeeping exact, so the waits for older loads do not drain these
-        codes = b.codes[(d.first_base >> 4) + lane];
-        inv = b.inval[(d.first_base >> 4) + lane];
+        // wave-uniform base + 32-bit lane offset: the scalar-base addressing form, no 64-bit vector addresses
+        const uint64_t w0 = d.first_base >> 4;
+        codes = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(b.codes + w0) + lane * 4u);
+        inv = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(b.inval + w0) + lane * 2u);
     };
     auto uniform64 = [](uint64_t v) {
         return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
     };
-    KidReadDesc dA, dB;
-    uint32_t cA, iA, cB, iB;
-    fetch_desc(gw, dA);
-    fetch_desc(gw + nw, dB);
-    fetch_words(dA, cA, iA);
-    for (uint64_t r = gw; r < b.n; r += 2 * nw) {
-        // read r (set A); meanwhile the words of read r + nw and the descriptor of read r + 2 nw travel
-        const uint64_t firstA = uniform64(dA.first_base);
-        const int64_t nkA = (int64_t)__builtin_amdgcn_readfirstlane(dA.n_kmers);
-        process_read(r, firstA, nkA, cA, iA, [&]() { fetch_words(dB, cB, iB); fetch_desc(r + 2 * nw, dA); });
-        if (r + nw >= b.n) break;
-        // read r + nw (set B); the words of read r + 2 nw and the descriptor of read r + 3 nw travel
-        const uint64_t firstB = uniform64(dB.first_base);
-        const int64_t nkB = (int64_t)__builtin_amdgcn_readfirstlane(dB.n_kmers);
-        process_read(r + nw, firstB, nkB, cB, iB, [&]() { fetch_words(dA, cA, iA); fetch_desc(r + 3 * nw, dB); });
+    // ---- phase 1: every read of one segment (<= 960 k-mers: all short-read data).  Longer ones are
+    // left to phase 2, so that their loop nest and 64-bit bookkeeping stay out of this loop's registers
+    bool any_long = false;
+    auto short_read = [&](const uint32_t r, const uint64_t first, const int32_t nk, const uint32_t st_codes,
+                          const uint32_t st_inv, auto &&prefetch) {
+        if (nk > KID_SEG_KMERS) { any_long = true; prefetch(); return; }
+        bool prefetched = false;
+        uint32_t final_t = 0;
+        uint32_t vfrow = 0, n_bad = 0;
+        if (nk > 0) {
+            const uint32_t sh = (uint32_t)first & 15u, segk = (uint32_t)nk, nb = segk + (uint32_t)k - 1;
+            KID_TICK(0);
+            KID_DRAIN();
+            KID_TICK(1); // waiting for the prefetched words
+#if defined(KID_ABLATE) && KID_ABLATE >= 4 // timing experiments only (results are wrong): no staging either
+            const bool seg_clean = true;
+            sink ^= st_codes ^ st_inv;
+#else
+            const bool seg_clean = stage(WA, st_codes, st_inv);
+#endif
+            for (uint32_t t0 = 0; t0 < segk; t0 += U * 64u) {
+                KidGroup<U> g;
+#if defined(KID_ABLATE)
+                // 1: front half without the header loads, no back half; 2: (see group_front) keys only; 3+: no front half
+                if (KID_ABLATE <= 2) {
+                    group_front(WA, sh, nb, segk, t0, seg_clean, g, n_bad, false);
+                    sink ^= g.hlo[0] ^ g.hlo[1] ^ (uint32_t)g.key[0] ^ (uint32_t)g.key[1] ^ (uint32_t)(g.key[0] >> 32) ^ (uint32_t)(g.key[1] >> 32);
+                }
+                if (!prefetched) { prefetch(); prefetched = true; }
+                continue;
+#endif
+                group_front(WA, sh, nb, segk, t0, seg_clean, g, n_bad);
+                if (!prefetched) { prefetch(); prefetched = true; }
+                KID_TICK(2); // stage + front half
+                KID_DRAIN();
+                KID_TICK(3); // waiting for the headers
+                group_back(g, final_t, vfrow);
+                KID_DRAIN();
+                KID_TICK(4); // back half incl. hit path
+            }
+            __builtin_amdgcn_wave_barrier(); // strip is rewritten by the next read
+        }
+        finish_read(r, final_t, (nk > 0 ? (uint32_t)nk : 0u) - n_bad);
+        if (!prefetched) prefetch();
+        KID_TICK(5);
+    };
+#if KID_PAIRS
+    // ---- batches whose reads all fit one group (<= U*64 k-mers: Illumina reads): hand-pipelined pairs.
+    // A wave is a chain of dependent round trips (strip, header, hit cell, ancestor row) that eight waves
+    // per SIMD do not cover, so two reads travel together: front half of A, front half of B (four header
+    // loads per lane in flight), the packed words of the next pair, then the back halves.  The compiler's
+    // waitcnt insertion drains vmcnt(0) whenever loads sit behind a branch or a store is pending, which
+    // serialises exactly these round trips; the loads of this loop are therefore issued from inline
+    // assembly, unconditionally (idle lanes read cell 0), and waited for with explicit counts.  Loads
+    // return in order, and anything the compiler issues in between (hit cells, atomics, the out_final
+    // store) only makes an explicit count stricter than needed.
+    if constexpr (PAIRK) {
+        uint32_t *const WB = WA + 104;
+        const uint32_t gw32 = (uint32_t)gw, nw32 = (uint32_t)nw;
+        auto flush_results = [&](const uint32_t i0, const uint32_t n) { // results of this wave's reads i0 .. i0+n-1 (n <= 64)
+            if (b.out_final && lane < n) kid_store_u32_nowait(&b.out_final[gw32 + (i0 + lane) * nw32], RB[(i0 + lane) & 63u]);
+        };
+        const uint32_t cnt = gw < b.n ? (uint32_t)((b.n - gw + nw - 1) / nw) : 0u; // reads of this wave: gw + i nw
+        const uint32_t lane4 = lane * 4u;
+        // descriptors, 64 at a time: lane l holds the one of read number blk + l of this wave
+        uint32_t blk = 0, dv_lo = 0, dv_hi = 0, dv_nk = 0;
+        auto load_block = [&]() {
+            const uint64_t rr = gw + (uint64_t)(blk + lane) * nw;
+            dv_lo = 0; dv_hi = 0; dv_nk = 0;
+            if (rr < b.n) {
+                const KidReadDesc d = b.desc[rr];
+                dv_lo = (uint32_t)d.first_base;
+                dv_hi = (uint32_t)(d.first_base >> 32);
+                dv_nk = d.n_kmers > 0 ? (uint32_t)d.n_kmers : 0u;
+            }
+        };
+        auto issue_words = [&](const uint32_t idx, uint32_t &c, uint32_t &iv) {
+            const uint64_t w0 = (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dv_hi, (int)idx) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)idx)) >> 4;
+            const uint32_t *const pc = b.codes + w0;
+            const uint16_t *const pi = b.inval + w0;
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(c) : "v"(lane4), "s"(pc) : "memory");
+            asm volatile("global_load_ushort %0, %1, %2" : "=v"(iv) : "v"(lane4 >> 1), "s"(pi) : "memory");
+        };
+        auto issue_header = [&](const KidGroup<U> &g, const int u) -> kid_u4 {
+            const uint4 *const p = db.table + (g.act[u] ? g.hlo[u] * KID_LINE_CELLS : 0u);
+            kid_u4 v;
+#if KID_NT
+            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(v) : "v"(p) : "memory");
+#else
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
+#endif
+            return v;
+        };
+        load_block();
+        uint32_t cA, iA, cB, iB;
+        issue_words(0u, cA, iA);
+        issue_words(1u, cB, iB);
+        for (uint32_t i = 0; i < cnt; i += 2) {
+            const uint32_t ia = i - blk;
+            const uint32_t nkA = (uint32_t)__builtin_amdgcn_readlane((int)dv_nk, (int)ia);
+            const uint32_t nkB = (uint32_t)__builtin_amdgcn_readlane((int)dv_nk, (int)(ia + 1u));
+            const uint32_t shA = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)ia) & 15u;
+            const uint32_t shB = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)(ia + 1u)) & 15u;
+            KidGroup<U> gA, gB;
+            uint32_t badA = 0, badB = 0, fA = 0, fB = 0, vA = 0, vB = 0;
+
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(cA), "+v"(iA) : : "memory"); // behind: the words of B
+            KID_TICK(0);
+            const bool clA = stage(WA, cA, iA);
+            group_front(WA, shA, nkA + (uint32_t)k - 1, nkA, 0u, clA, gA, badA, false);
+            kid_u4 hA0 = issue_header(gA, 0), hA1 = issue_header(gA, 1);
+            KID_TICK(1);
+
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(cB), "+v"(iB) : : "memory"); // behind: the headers of A
+            KID_TICK(2);
+            const bool clB = stage(WB, cB, iB);
+            group_front(WB, shB, nkB + (uint32_t)k - 1, nkB, 0u, clB, gB, badB, false);
+            kid_u4 hB0 = issue_header(gB, 0), hB1 = issue_header(gB, 1);
+            KID_TICK(3);
+
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(hA0), "+v"(hA1) : : "memory"); // behind: the headers of B
+            KID_TICK(4);
+            gA.hd[0] = make_uint4(hA0.x, hA0.y, hA0.z, hA0.w);
+            gA.hd[1] = make_uint4(hA1.x, hA1.y, hA1.z, hA1.w);
+            group_back(gA, fA, vA);
+            finish_read(gw32 + i * nw32, fA, nkA - badA);
+            if (lane == 0) RB[i & 63u] = fA;
+            KID_TICK(5);
+
+            // the packed words of the next pair are requested as late as their registers allow (from the
+            // next descriptor block if need be): A's behind A's back half, B's behind B's
+            if (ia + 3u > 63u) { blk = i + 2u; load_block(); }
+            issue_words(i + 2u - blk, cA, iA);
+
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(hB0), "+v"(hB1) : : "memory"); // behind: the next words of A
+            KID_TICK(6);
+            gB.hd[0] = make_uint4(hB0.x, hB0.y, hB0.z, hB0.w);
+            gB.hd[1] = make_uint4(hB1.x, hB1.y, hB1.z, hB1.w);
+            group_back(gB, fB, vB);
+            if (i + 1u < cnt) finish_read(gw32 + (i + 1u) * nw32, fB, nkB - badB);
+            if (lane == 0) RB[(i + 1u) & 63u] = fB;
+            issue_words(i + 3u - blk, cB, iB);
+            KID_TICK(7);
+            if (((i + 2u) & 63u) == 0u) flush_results(i + 2u - 64u, 64u);
+            __builtin_amdgcn_wave_barrier(); // the strips are rewritten by the next pair
+        }
+        if (cnt & 63u) flush_results(cnt & ~63u, cnt & 63u);
+        flush_seen(sq_n);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cA), "+v"(iA), "+v"(cB), "+v"(iB) : : "memory");
     }
-    if (!HIST && pend_n && lane == 0) atomicAdd(&s.gcount[pend_t], (unsigned long long)pend_n);
+#endif
+    if constexpr (!PAIRK) {
+        // Software pipeline, unrolled by two with two named register sets (A, B) so that nothing is
+        // copied between stages: the descriptor of a read is requested two reads ahead (scalar loads)
+        // and its first packed words one read ahead; the waits the compiler places in front of their
+        // first use land behind a whole read's worth of work.  32-bit read indices (n < 2^31).
+        const uint32_t n32 = (uint32_t)b.n, gw32 = (uint32_t)gw, nw32 = (uint32_t)nw;
+        KidReadDesc dA, dB;
+        uint32_t cA, iA, cB, iB;
+        fetch_desc(gw32, dA);
+        fetch_desc(gw32 + nw32, dB);
+        fetch_words(dA, cA, iA);
+        for (uint32_t r = gw32; r < n32; r += 2 * nw32) {
+            short_read(r, uniform64(dA.first_base), __builtin_amdgcn_readfirstlane(dA.n_kmers), cA, iA,
+                       [&]() { fetch_words(dB, cB, iB); fetch_desc(r + 2 * nw32, dA); });
+            if (r + nw32 >= n32) break;
+            short_read(r + nw32, uniform64(dB.first_base), __builtin_amdgcn_readfirstlane(dB.n_kmers), cB, iB,
+                       [&]() { fetch_words(dA, cA, iA); fetch_desc(r + 3 * nw32, dB); });
+        }
+    }
+    // ---- phase 2: the long reads this wave met (FASTA records, long-read data), one at a time
+    if (!PAIRK && any_long) {
+        for (uint64_t r = gw; r < b.n; r += nw) {
+            const KidReadDesc d = descs[r];
+            const int64_t nk = (int64_t)__builtin_amdgcn_readfirstlane(d.n_kmers);
+            if (nk <= KID_SEG_KMERS) continue;
+            uint32_t c0, i0;
+            fetch_words(d, c0, i0);
+            process_read(r, uniform64(d.first_base), nk, c0, i0, []() {});
+        }
+    }
+    if (!HIST && pend_n && lane == 0) atomicAdd(&rare->gcount[pend_t], (unsigned long long)pend_n);
 
     // ---- flush
     if (HIST) {
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < hist_words; i += blockDim.x) {
             const uint32_t v = hist[i];
-            if (v) atomicAdd(&s.gcount[i], (unsigned long long)v);
+            if (v) atomicAdd(&rare->gcount[i], (unsigned long long)v);
         }
     }
-    unsigned long long tl = n_lookups, tp = n_probes;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        tl += __shfl_xor(tl, o);
-        tp += __shfl_xor(tp, o);
-    }
+#ifdef KID_PROFILE
+    KID_TICK(8);
+    if (lane == 0) for (int i = 0; i < 10; i++) atomicAdd(&rare->stats[8 + i], prof[i]);
+#endif
+#ifdef KID_ABLATE
+    if (sink == 0x12345678u) atomicAdd(&rare->stats[7], 1ull);
+#endif
     if (lane == 0) {
-        if (n_reads) atomicAdd(&s.stats[0], (unsigned long long)n_reads);
-        if (tl) atomicAdd(&s.stats[1], tl);
-        if (tp) atomicAdd(&s.stats[2], tp);
-        if (n_hits) atomicAdd(&s.stats[3], (unsigned long long)n_hits);
+        const unsigned long long tl = *WL, n_reads = gw < b.n ? (b.n - gw + nw - 1) / nw : 0ull; // reads r = gw + i nw
+        const uint32_t n_hits = WC[2];
+        const unsigned long long te = WC[3];
+        if (n_reads) atomicAdd(&rare->stats[0], n_reads);
+        if (tl) atomicAdd(&rare->stats[1], tl);
+        if (tl + te) atomicAdd(&rare->stats[2], tl + te); // cells read: one per lookup plus the probes beyond the first
+        if (n_hits) atomicAdd(&rare->stats[3], (unsigned long long)n_hits);
     }
 }
 
