@@ -19,9 +19,10 @@
 #define KID_WAVE 64
 #define KID_SEG_KMERS 960  // k-mers per read segment: 960 + 30 bases + 15 alignment slack <= 64 chunks of 16 B
 #define KID_WAVE_LDS_WORDS 104 // per wave, general loops: 66 packed-base words + 34 invalid-mask words + 4 counters
-// pair kernel: + a second strip (100), the per-read results of 64 reads (64), a queue of hit cells (128)
-#define KID_PAIR_LDS_WORDS 396
-#define KID_SEENQ_WORDS 128
+// pair kernel: + a second strip (100) and the queue of unresolved lookups (3 words + 1 tag byte per entry)
+#define KID_CQ_CAP 160   // a read appends at most 128 entries to fewer than KID_CQ_FLUSH queued ones
+#define KID_CQ_FLUSH 32
+#define KID_PAIR_LDS_WORDS (204 + 3 * KID_CQ_CAP + KID_CQ_CAP / 4 + 64) // ... and the results of 64 reads
 #if defined(KID_ABLATE) && KID_ABLATE >= 2
 #define KID_ABLATE_NOMIN 1
 #else
@@ -404,18 +405,6 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
     unsigned long long *const WL = reinterpret_cast<unsigned long long *>(WC);
     if (lane < 4) WC[lane] = 0;
     uint32_t pend_t = 0, pend_n = 0;       // !HIST: run-length buffer in front of the global gcount atomics
-    // Pair kernel: global writes are batched.  A pending store or atomic shares vmcnt with the loads, and
-    // every vmcnt(0) the compiler places (hit cells, ancestor rows) would sit out its acknowledgement;
-    // so the per-read results wait in RB (one scattered store per 64 reads) and the hit cells in SQ
-    // (64 atomics at a time).
-    uint32_t *const RB = WA + 204, *const SQ = WA + 268;
-    uint32_t sq_n = 0; // wave-uniform fill of SQ
-    auto flush_seen = [&](const uint32_t n) { // the first n (<= 64) entries of SQ
-        if (lane < n) {
-            const uint32_t slot = SQ[lane];
-            kid_atomic_or_nowait(&s.seen[slot >> 5], 1u << (slot & 31u));
-        }
-    };
 #ifdef KID_ABLATE
     uint32_t sink = 0;
 #endif
@@ -623,27 +612,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             row[u] = make_uint4(0, 0, 0, 0);
             if (tgt[u] > 0) {
                 if (ROWS) row[u] = db.rows[tgt[u]];
-                if (!PAIRK && tgt[u] > 1) kid_atomic_or_nowait(&s.seen[slot[u] >> 5], 1u << (slot[u] & 31u));
-            }
-            if (PAIRK) { // append the hit cells to SQ (wave-uniform bookkeeping), writing out 64 at a time
-                const uint64_t qm = __ballot(tgt[u] > 1);
-                const uint32_t qc = (uint32_t)__popcll(qm);
-                if (qc) {
-                    if (sq_n + qc > KID_SEENQ_WORDS) { // cannot happen with sq_n < 64 and qc <= 64; kept as a guard
-                        flush_seen(sq_n < 64u ? sq_n : 64u);
-                        sq_n = 0;
-                    }
-                    if (tgt[u] > 1) SQ[sq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u))] = slot[u];
-                    sq_n += qc;
-                    if (sq_n >= 64u) {
-                        flush_seen(64u);
-                        const uint32_t rest = sq_n - 64u;    // < 64: move the tail to the front
-                        uint32_t t = 0;
-                        if (lane < rest) t = SQ[64u + lane];
-                        if (lane < rest) SQ[lane] = t;
-                        sq_n = rest;
-                    }
-                }
+                if (tgt[u] > 1) kid_atomic_or_nowait(&s.seen[slot[u] >> 5], 1u << (slot[u] & 31u));
             }
             hitm[u] = __ballot(tgt[u] > 0);
             nh += (uint32_t)__popcll(hitm[u]);
@@ -700,7 +669,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                 pend_n = 1;
             }
         }
-        if (!PAIRK && lane == 0 && b.out_final) kid_store_u32_nowait(&b.out_final[r], final_t);
+        if (lane == 0 && b.out_final) kid_store_u32_nowait(&b.out_final[r], final_t);
     };
 
     // ---- a whole read of any length on its own, given its descriptor and its first packed segment.
@@ -817,9 +786,6 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
     if constexpr (PAIRK) {
         uint32_t *const WB = WA + 104;
         const uint32_t gw32 = (uint32_t)gw, nw32 = (uint32_t)nw;
-        auto flush_results = [&](const uint32_t i0, const uint32_t n) { // results of this wave's reads i0 .. i0+n-1 (n <= 64)
-            if (b.out_final && lane < n) kid_store_u32_nowait(&b.out_final[gw32 + (i0 + lane) * nw32], RB[(i0 + lane) & 63u]);
-        };
         const uint32_t cnt = gw < b.n ? (uint32_t)((b.n - gw + nw - 1) / nw) : 0u; // reads of this wave: gw + i nw
         const uint32_t lane4 = lane * 4u;
         // descriptors, 64 at a time: lane l holds the one of read number blk + l of this wave
@@ -852,6 +818,186 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
 #endif
             return v;
         };
+        // ---- back half, deferred.  A lookup whose header shows a fingerprint match (or a chained line)
+        // is not followed up on the spot -- that would put two more dependent round trips (hit cell,
+        // ancestor row) on every second read -- but queued in LDS; queued lookups are resolved 64 at a
+        // time, one per lane, and folded read by read (entries are in read order, then window order).
+        uint32_t *const CQ_klo = WA + 204, *const CQ_khi = CQ_klo + KID_CQ_CAP, *const CQ_lw = CQ_khi + KID_CQ_CAP;
+        uint8_t *const CQ_tag = reinterpret_cast<uint8_t *>(CQ_lw + KID_CQ_CAP); // read number mod 64
+        // per-read results wait in LDS for one scattered store per 64 reads: a pending store shares vmcnt
+        // with the loads, and the explicit counts of the loop would have to sit out its acknowledgement
+        uint32_t *const RB = CQ_lw + KID_CQ_CAP + KID_CQ_CAP / 4;
+        auto flush_results = [&](const uint32_t i0, const uint32_t n) { // this wave's reads i0 .. i0+n-1 (n <= 64)
+            if (b.out_final && lane < n) kid_store_u32_nowait(&b.out_final[gw32 + (i0 + lane) * nw32], RB[(i0 + lane) & 63u]);
+        };
+        uint32_t qn = 0;        // wave-uniform fill of the queue
+        uint32_t n_lookups = 0; // wave-uniform: below 2^32 per wave and launch (n < 2^31 reads of <= 128 k-mers, 8192 waves)
+        auto commit = [&](const uint32_t i, const uint32_t final_t) { // gcount[final]++ (:605), per-read output
+            if (HIST) {
+                if (lane == 0) atomicAdd(&hist[final_t >> 1], 1u << (16u * (final_t & 1u)));
+            } else if (final_t == pend_t) {
+                pend_n++;
+            } else {
+                if (pend_n && lane == 0) atomicAdd(&rare->gcount[pend_t], (unsigned long long)pend_n);
+                pend_t = final_t;
+                pend_n = 1;
+            }
+            if (lane == 0) RB[i & 63u] = final_t;
+        };
+        auto resolve_all = [&](const uint32_t i_now) { // i_now: number of the newest queued read (all are within 63 of it)
+#if defined(KID_ABLATE_DEF) && KID_ABLATE_DEF == 2 // timing experiments only: queue filled, never resolved
+            qn = 0;
+            return;
+#endif
+            uint32_t cur_tag = 0xFFFFFFFFu, final_t = 0, vfrow = 0; // no read open
+            auto commit_tag = [&](const uint32_t tag, const uint32_t f) {
+                commit(i_now - ((i_now - tag) & 63u), f);
+            };
+            for (uint32_t base = 0; base < qn; base += 64u) {
+                const uint32_t n = qn - base < 64u ? qn - base : 64u;
+                const bool valid = lane < n;
+                uint32_t klo = 0, khi = 0, ln = 0, tag = 0;
+                if (valid) { klo = CQ_klo[base + lane]; khi = CQ_khi[base + lane]; ln = CQ_lw[base + lane]; tag = CQ_tag[base + lane]; }
+                // the header once more (the queue keeps only the line: working out the candidates at
+                // queueing time would cost the hot loop ~45 instructions per read with a match)
+                uint32_t tgt = 0, slot = 0, mu = 0;
+                const uint32_t fp = kid_key_fp(((uint64_t)khi << 32) | klo);
+                bool fu = false;
+                if (valid) {
+                    const uint4 h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
+                    mu = kid_hdr_cand(h, fp);
+                    fu = (h.w >> 16) >= KID_HDR_FULL;
+                }
+                if (mu) { // the first candidate of every entry in one round trip: almost always the key itself
+                    const uint32_t idx = ln * KID_LINE_CELLS + 1u + kid_cand_entry((uint32_t)__builtin_ctz(mu));
+                    mu &= mu - 1;
+                    const uint4 c = kid_load_cell(db.table, idx);
+                    atomicAdd(&WC[3], 1u);
+                    if (c.z != 0 && c.x == klo && c.y == khi) { tgt = c.z; slot = idx; }
+                }
+                bool go = valid && tgt == 0 && (mu != 0 || fu);
+                while (go) { // a second candidate (1e-4 of the lookups) or a chained line (1e-5)
+                    if (mu) {
+                        const uint32_t j = kid_cand_entry((uint32_t)__builtin_ctz(mu));
+                        mu &= mu - 1;
+                        const uint32_t ix = ln * KID_LINE_CELLS + 1u + j;
+                        const uint4 cc = kid_load_cell(db.table, ix);
+                        atomicAdd(&WC[3], 1u);
+                        if (cc.z != 0 && cc.x == klo && cc.y == khi) { tgt = cc.z; slot = ix; go = false; }
+                    } else if (fu) {
+                        ln = (ln + 1u) & rare->line_mask;
+                        const uint4 h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
+                        atomicAdd(&WC[3], 1u);
+                        mu = kid_hdr_cand(h, fp);
+                        fu = (h.w >> 16) >= KID_HDR_FULL;
+                    } else go = false;
+                }
+                uint4 row = make_uint4(0, 0, 0, 0);
+                if (tgt > 0) {
+                    if (ROWS) row = db.rows[tgt];
+                    if (tgt > 1) kid_atomic_or_nowait(&s.seen[slot >> 5], 1u << (slot & 31u));
+                }
+                const uint64_t hitm = __ballot(tgt > 0);
+                if (hitm && lane == 0) atomicAdd(&WC[2], (uint32_t)__popcll(hitm));
+                // Fold read by read, one lane per read: entries of a read are neighbours (a change of tag
+                // starts the next read); the first lane of a run walks its run in window order, fetching
+                // (target, ancestor row) of entry lane + t with ds_bpermute.  The left fold of msca over
+                // the hits of a read, newkmer_10nx.cpp:588-595.
+                const uint32_t tprev = (uint32_t)__shfl_up((int)tag, 1);
+                const bool head = valid && (lane == 0 || tag != tprev);
+                const uint64_t hm = __ballot(head);
+                const uint64_t above = lane < 63u ? (hm >> (lane + 1u)) : 0ull;
+                const uint32_t len = above ? (uint32_t)__builtin_ctzll(above) + 1u : n - lane; // entries of this run (head lanes)
+                uint32_t f = 0;
+                uint4 fr = make_uint4(0, 0, 0, 0);
+                if (lane == 0 && cur_tag != 0xFFFFFFFFu) {
+                    if (valid && tag == cur_tag) { // the run continues the read left open by the chunk before
+                        f = final_t;
+                        fr.x = (uint32_t)__builtin_amdgcn_readlane((int)vfrow, 0);
+                        fr.y = (uint32_t)__builtin_amdgcn_readlane((int)vfrow, 1);
+                        fr.z = (uint32_t)__builtin_amdgcn_readlane((int)vfrow, 2);
+                        fr.w = (uint32_t)__builtin_amdgcn_readlane((int)vfrow, 3);
+                    }
+                }
+                if (cur_tag != 0xFFFFFFFFu && (uint32_t)__builtin_amdgcn_readfirstlane((int)tag) != cur_tag) commit_tag(cur_tag, final_t);
+                for (uint32_t t = 0; __ballot(head && t < len) != 0; t++) {
+                    const int src = (int)(((lane + t) & 63u) << 2);
+                    const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)tgt);
+                    uint4 rx;
+                    rx.x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)row.x);
+                    rx.y = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)row.y);
+                    rx.z = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)row.z);
+                    rx.w = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)row.w);
+                    if (head && t < len && x != 0 && x != f) { // msca(x,x) = x
+                        if (f != 0) {
+                            if (ROWS) {
+                                uint4 ro;
+                                f = kid_msca_rows(x, rx, f, fr, ro);
+                                fr = ro;
+                            } else {
+                                f = kid_msca_climb(db, x, f);
+                            }
+                        } else {
+                            f = x; // :592-595
+                            fr = rx;
+                        }
+                    }
+                }
+                // every run but the last one is a finished read; the last one too unless a chunk follows
+                const uint32_t last = 63u - (uint32_t)__builtin_clzll(hm); // hm != 0: n >= 1
+                const bool more_chunks = base + 64u < qn;
+                if (head && (lane != last || !more_chunks)) {
+                    if (HIST) atomicAdd(&hist[f >> 1], 1u << (16u * (f & 1u)));
+                    else atomicAdd(&rare->gcount[f], 1ull);
+                    RB[tag] = f; // tag = read number mod 64
+                }
+                if (more_chunks) {
+                    cur_tag = (uint32_t)__builtin_amdgcn_readlane((int)tag, (int)last);
+                    final_t = (uint32_t)__builtin_amdgcn_readlane((int)f, (int)last);
+                    const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)fr.x, (int)last), a1 = (uint32_t)__builtin_amdgcn_readlane((int)fr.y, (int)last);
+                    const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)fr.z, (int)last), a3 = (uint32_t)__builtin_amdgcn_readlane((int)fr.w, (int)last);
+                    vfrow = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : lane == 3 ? a3 : vfrow;
+                } else {
+                    cur_tag = 0xFFFFFFFFu;
+                }
+            }
+            if (cur_tag != 0xFFFFFFFFu) commit_tag(cur_tag, final_t);
+            qn = 0;
+        };
+        // header test of one read; its unsettled lookups go to the queue, a read without any is done
+        auto back_deferred = [&](const KidGroup<U> &g, const uint32_t i, const bool exists, const uint32_t n_valid) {
+            if (exists) n_lookups += n_valid;
+            uint32_t fp[U];
+            bool mm[U], more = false;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                fp[u] = (g.fpp >> (16 * u)) & 0xFFFFu;
+                mm[u] = g.act[u] && (kid_hdr_any(g.hd[u], fp[u]) || (g.hd[u].w >> 16) >= KID_HDR_FULL);
+                more |= mm[u];
+            }
+#if defined(KID_ABLATE_DEF) && KID_ABLATE_DEF == 1 // timing experiments only: no queue at all
+            if (true) {
+#else
+            if (__ballot(more) == 0) { // (wave-uniform) ~99 % of the lookups are settled by their header
+#endif
+                if (exists) commit(i, 0u);
+                return;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint64_t qm = __ballot(mm[u]);
+                if (qm == 0) continue;
+                if (mm[u]) {
+                    const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
+                    CQ_klo[pos] = (uint32_t)g.key[u];
+                    CQ_khi[pos] = (uint32_t)(g.key[u] >> 32);
+                    CQ_lw[pos] = g.hlo[u];
+                    CQ_tag[pos] = (uint8_t)(i & 63u);
+                }
+                qn += (uint32_t)__popcll(qm);
+            }
+            if (qn >= KID_CQ_FLUSH) resolve_all(i);
+        };
         load_block();
         uint32_t cA, iA, cB, iB;
         issue_words(0u, cA, iA);
@@ -863,7 +1009,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             const uint32_t shA = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)ia) & 15u;
             const uint32_t shB = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)(ia + 1u)) & 15u;
             KidGroup<U> gA, gB;
-            uint32_t badA = 0, badB = 0, fA = 0, fB = 0, vA = 0, vB = 0;
+            uint32_t badA = 0, badB = 0;
 
             asm volatile("s_waitcnt vmcnt(2)" : "+v"(cA), "+v"(iA) : : "memory"); // behind: the words of B
             KID_TICK(0);
@@ -883,9 +1029,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             KID_TICK(4);
             gA.hd[0] = make_uint4(hA0.x, hA0.y, hA0.z, hA0.w);
             gA.hd[1] = make_uint4(hA1.x, hA1.y, hA1.z, hA1.w);
-            group_back(gA, fA, vA);
-            finish_read(gw32 + i * nw32, fA, nkA - badA);
-            if (lane == 0) RB[i & 63u] = fA;
+            back_deferred(gA, i, true, nkA - badA);
             KID_TICK(5);
 
             // the packed words of the next pair are requested as late as their registers allow (from the
@@ -897,16 +1041,18 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             KID_TICK(6);
             gB.hd[0] = make_uint4(hB0.x, hB0.y, hB0.z, hB0.w);
             gB.hd[1] = make_uint4(hB1.x, hB1.y, hB1.z, hB1.w);
-            group_back(gB, fB, vB);
-            if (i + 1u < cnt) finish_read(gw32 + (i + 1u) * nw32, fB, nkB - badB);
-            if (lane == 0) RB[(i + 1u) & 63u] = fB;
+            back_deferred(gB, i + 1u, i + 1u < cnt, nkB - badB);
             issue_words(i + 3u - blk, cB, iB);
             KID_TICK(7);
-            if (((i + 2u) & 63u) == 0u) flush_results(i + 2u - 64u, 64u);
+            if (((i + 2u) & 63u) == 0u) { // tags and result slots are read numbers mod 64
+                if (qn) resolve_all(i + 1u);
+                flush_results(i + 2u - 64u, 64u);
+            }
             __builtin_amdgcn_wave_barrier(); // the strips are rewritten by the next pair
         }
+        if (qn) resolve_all(cnt - 1u);
         if (cnt & 63u) flush_results(cnt & ~63u, cnt & 63u);
-        flush_seen(sq_n);
+        if (lane == 0) atomicAdd(WL, (unsigned long long)n_lookups);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(cA), "+v"(iA), "+v"(cB), "+v"(iB) : : "memory");
     }
 #endif
@@ -942,12 +1088,16 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
     }
     if (!HIST && pend_n && lane == 0) atomicAdd(&rare->gcount[pend_t], (unsigned long long)pend_n);
 
-    // ---- flush
+    // ---- flush (the pair kernel's histogram packs two 16-bit counters per word: the host keeps a
+    // workgroup below 65536 reads per launch)
     if (HIST) {
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < hist_words; i += blockDim.x) {
             const uint32_t v = hist[i];
-            if (v) atomicAdd(&rare->gcount[i], (unsigned long long)v);
+            if (PAIRK) {
+                if (v & 0xFFFFu) atomicAdd(&rare->gcount[2u * i], (unsigned long long)(v & 0xFFFFu));
+                if (v >> 16) atomicAdd(&rare->gcount[2u * i + 1u], (unsigned long long)(v >> 16));
+            } else if (v) atomicAdd(&rare->gcount[i], (unsigned long long)v);
         }
     }
 #ifdef KID_PROFILE
