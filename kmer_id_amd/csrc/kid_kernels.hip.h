@@ -19,10 +19,11 @@
 #define KID_WAVE 64
 #define KID_SEG_KMERS 960  // k-mers per read segment: 960 + 30 bases + 15 alignment slack <= 64 chunks of 16 B
 #define KID_WAVE_LDS_WORDS 104 // per wave, general loops: 66 packed-base words + 34 invalid-mask words + 4 counters
-// pair kernel: + a second strip (100) and the queue of unresolved lookups (3 words + 1 tag byte per entry)
-#define KID_CQ_CAP 160   // a read appends at most 128 entries to fewer than KID_CQ_FLUSH queued ones
-#define KID_CQ_FLUSH 32
-#define KID_PAIR_LDS_WORDS (204 + 3 * KID_CQ_CAP + KID_CQ_CAP / 4 + 64) // ... and the results of 64 reads
+// pair kernel (no strips): 4 counters, the queue of unresolved lookups (3 words + 1 tag byte per entry) and the
+// results of 64 reads
+#define KID_CQ_CAP 192   // a read appends at most 128 entries to fewer than KID_CQ_FLUSH queued ones
+#define KID_CQ_FLUSH 64
+#define KID_PAIR_LDS_WORDS (4 + 3 * KID_CQ_CAP + KID_CQ_CAP / 4 + 64)
 #if defined(KID_ABLATE) && KID_ABLATE >= 2
 #define KID_ABLATE_NOMIN 1
 #else
@@ -42,9 +43,6 @@ typedef uint32_t kid_u4 __attribute__((ext_vector_type(4)));
 // 49 -> 54 G random cells/s on a 16 GiB region).
 #ifndef KID_NT
 #define KID_NT 1
-#endif
-#ifndef KID_PAIR
-#define KID_PAIR 0
 #endif
 // Fire-and-forget global writes of the classify kernel (per-read result, seen-bitmap bits).  Issued
 // from inline assembly so that the compiler's waitcnt insertion does not know them: on gfx9 a pending
@@ -312,7 +310,10 @@ __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, u
     // largest read of the batch, tagged with the batch number so that the word never needs a reset
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)mx, o); mx = y > mx ? y : mx; }
-    if ((threadIdx.x & 63u) == 0) atomicMax(&rare->batch_max, ((unsigned long long)seq << 32) | mx);
+    if ((threadIdx.x & 63u) == 0) { // one atomic for the first wave to see a new maximum, a plain load for the others
+        const unsigned long long v = ((unsigned long long)seq << 32) | mx;
+        if (v > *reinterpret_cast<volatile unsigned long long *>(&rare->batch_max)) atomicMax(&rare->batch_max, v);
+    }
     if (bad) atomicAdd(&stats[4], (unsigned long long)bad);
 }
 
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
     // scalar registers (80 per wave at this occupancy, and the hot loop wants them all): lookups and
     // hits accumulate in the wave's LDS words, the msca row of the running result in lanes 0-3 of a
     // vector register, the probes beyond the first in a per-lane counter.
-    uint32_t *const WC = WA + 100; // [0..1] lookups (64 bits), [2] hits, [3] probes beyond the first of a lookup
+    uint32_t *const WC = WA + (PAIRK ? 0 : 100); // [0..1] lookups (64 bits), [2] hits, [3] probes beyond the first of a lookup
     unsigned long long *const WL = reinterpret_cast<unsigned long long *>(WC);
     if (lane < 4) WC[lane] = 0;
     uint32_t pend_t = 0, pend_n = 0;       // !HIST: run-length buffer in front of the global gcount atomics
@@ -432,8 +433,21 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
 
     // ---- 2, 3a. windows [t0, t0 + U*64) of the staged segment: keys, table line, header loads issued
     auto group_front = [&](const uint32_t *W, const uint32_t sh, const uint32_t nb, const uint32_t segk, const uint32_t t0,
-                           const bool seg_clean, KidGroup<U> &g, uint32_t &n_bad, const bool issue_loads = true) {
-        const uint32_t *IM = W + 66;
+                           const bool seg_clean, KidGroup<U> &g, uint32_t &n_bad, const bool issue_loads = true,
+                           const uint32_t wcodes = 0, const uint32_t winv = 0) {
+        // W == nullptr (pair kernel): no LDS strip; lane c holds packed word c and mask c of the read in
+        // (wcodes, winv) and a window fetches its three words with ds_bpermute -- one LDS round trip
+        // instead of write + barrier + read.  Needs the whole read inside 64 words, which a group is.
+        const bool direct = (W == nullptr);
+        auto word = [&](const uint32_t idx) -> uint32_t {
+            return direct ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)wcodes) : W[idx];
+        };
+        auto mask32 = [&](const uint32_t idx) -> uint32_t { // invalid-mask bits of bases 32 idx .. 32 idx + 31
+            if (!direct) return (W + 66)[idx];
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 3), (int)winv);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx << 3) + 4u), (int)winv);
+            return (lo & 0xFFFFu) | (hi << 16);
+        };
         uint32_t P[U + 1], S[U]; // minloc: row prefix / suffix minima of the hashed m-mers
         const uint32_t pmax = sh + nb - (uint32_t)mlen; // last m-mer start inside the segment
 #pragma unroll
@@ -445,8 +459,8 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             uint32_t p = sh + i;
             p = MINLOC ? (p < pmax ? p : pmax) : sh + (i < segk ? i : 0u);
             const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
-            const uint64_t A = ((uint64_t)W[w0] << 32) | W[w0 + 1];
-            const uint64_t B = W[w0 + 2];
+            const uint64_t A = ((uint64_t)word(w0) << 32) | word(w0 + 1);
+            const uint64_t B = word(w0 + 2);
             const uint64_t x = (A << o2) | ((B << o2) >> 32);
             const uint64_t keyF = x >> (64 - 2 * k);
             // one reversal of the 32-base window serves both reverse complements: base j of the window
@@ -455,7 +469,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             const uint64_t keyR = nrv & (~0ull >> (64 - 2 * k));
             bool valid = (i < segk);
             if (!seg_clean) { // rare: some base of the segment is not ACGTacgt
-                const uint64_t im = (((uint64_t)IM[(p >> 5) + 1] << 32) | IM[p >> 5]) >> (p & 31u);
+                const uint64_t im = (((uint64_t)mask32((p >> 5) + 1) << 32) | mask32(p >> 5)) >> (p & 31u);
                 const bool ok = ((im & ((1ull << k) - 1ull)) == 0);
                 n_bad += (uint32_t)__popcll(__ballot(valid && !ok));
                 valid = valid && ok;
@@ -481,7 +495,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                 uint32_t p = sh + t0 + (uint32_t)U * 64u + lane;
                 p = p < pmax ? p : pmax;
                 const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
-                const uint64_t A = ((uint64_t)W[w0] << 32) | W[w0 + 1];
+                const uint64_t A = ((uint64_t)word(w0) << 32) | word(w0 + 1);
                 P[U] = kid_row_prefix_min(kid_mmer_hash((uint32_t)((A << o2) >> (64 - 2 * mlen)), mlen));
             }
             // ... and their minimum over every window a[p..p+win-1].  With q = p mod 16: the window
@@ -520,9 +534,6 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                 more |= mm[u] != 0;
             }
             if (__ballot(more) == 0) return; // (wave-uniform) ~99 % of the lanes are settled by their header
-#ifdef KID_ABLATE_NOHIT // timing experiment only: pretend no fingerprint ever matches
-            if (PAIRK) return;
-#endif
             // fingerprint matches (almost always the key itself): the first candidate cell of every
             // pending lookup is requested at once -- one round trip for the whole group.  From here on a
             // header is only its candidate set and its "line continues" flag.
@@ -710,11 +721,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
 
     auto fetch_desc = [&](uint32_t r, KidReadDesc &d) {
         d.first_base = 0; d.n_kmers = 0; d.pad = 0;
-#ifdef KID_FIXED_HACK // experiment only: descriptors of fixed-length reads computed, not loaded
-        if (r < (uint32_t)b.n) { d.first_base = (uint64_t)r * KID_FIXED_HACK; d.n_kmers = KID_FIXED_HACK - 29; }
-#else
         if (r < (uint32_t)b.n) d = descs[r];
-#endif
     };
     auto fetch_words = [&](const KidReadDesc &d, uint32_t &codes, uint32_t &inv) {
         // unconditional (the scratch arrays are padded by 64 entries): a fixed number of loads keeps the
@@ -784,7 +791,6 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
     // return in order, and anything the compiler issues in between (hit cells, atomics, the out_final
     // store) only makes an explicit count stricter than needed.
     if constexpr (PAIRK) {
-        uint32_t *const WB = WA + 104;
         const uint32_t gw32 = (uint32_t)gw, nw32 = (uint32_t)nw;
         const uint32_t cnt = gw < b.n ? (uint32_t)((b.n - gw + nw - 1) / nw) : 0u; // reads of this wave: gw + i nw
         const uint32_t lane4 = lane * 4u;
@@ -822,7 +828,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         // is not followed up on the spot -- that would put two more dependent round trips (hit cell,
         // ancestor row) on every second read -- but queued in LDS; queued lookups are resolved 64 at a
         // time, one per lane, and folded read by read (entries are in read order, then window order).
-        uint32_t *const CQ_klo = WA + 204, *const CQ_khi = CQ_klo + KID_CQ_CAP, *const CQ_lw = CQ_khi + KID_CQ_CAP;
+        uint32_t *const CQ_klo = WA + 4, *const CQ_khi = CQ_klo + KID_CQ_CAP, *const CQ_lw = CQ_khi + KID_CQ_CAP;
         uint8_t *const CQ_tag = reinterpret_cast<uint8_t *>(CQ_lw + KID_CQ_CAP); // read number mod 64
         // per-read results wait in LDS for one scattered store per 64 reads: a pending store shares vmcnt
         // with the loads, and the explicit counts of the loop would have to sit out its acknowledgement
@@ -845,10 +851,6 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             if (lane == 0) RB[i & 63u] = final_t;
         };
         auto resolve_all = [&](const uint32_t i_now) { // i_now: number of the newest queued read (all are within 63 of it)
-#if defined(KID_ABLATE_DEF) && KID_ABLATE_DEF == 2 // timing experiments only: queue filled, never resolved
-            qn = 0;
-            return;
-#endif
             uint32_t cur_tag = 0xFFFFFFFFu, final_t = 0, vfrow = 0; // no read open
             auto commit_tag = [&](const uint32_t tag, const uint32_t f) {
                 commit(i_now - ((i_now - tag) & 63u), f);
@@ -975,11 +977,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                 mm[u] = g.act[u] && (kid_hdr_any(g.hd[u], fp[u]) || (g.hd[u].w >> 16) >= KID_HDR_FULL);
                 more |= mm[u];
             }
-#if defined(KID_ABLATE_DEF) && KID_ABLATE_DEF == 1 // timing experiments only: no queue at all
-            if (true) {
-#else
             if (__ballot(more) == 0) { // (wave-uniform) ~99 % of the lookups are settled by their header
-#endif
                 if (exists) commit(i, 0u);
                 return;
             }
@@ -1013,15 +1011,15 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
 
             asm volatile("s_waitcnt vmcnt(2)" : "+v"(cA), "+v"(iA) : : "memory"); // behind: the words of B
             KID_TICK(0);
-            const bool clA = stage(WA, cA, iA);
-            group_front(WA, shA, nkA + (uint32_t)k - 1, nkA, 0u, clA, gA, badA, false);
+            const bool clA = (__ballot(iA != 0) == 0); // no base of the read resets a window
+            group_front(nullptr, shA, nkA + (uint32_t)k - 1, nkA, 0u, clA, gA, badA, false, cA, iA);
             kid_u4 hA0 = issue_header(gA, 0), hA1 = issue_header(gA, 1);
             KID_TICK(1);
 
             asm volatile("s_waitcnt vmcnt(2)" : "+v"(cB), "+v"(iB) : : "memory"); // behind: the headers of A
             KID_TICK(2);
-            const bool clB = stage(WB, cB, iB);
-            group_front(WB, shB, nkB + (uint32_t)k - 1, nkB, 0u, clB, gB, badB, false);
+            const bool clB = (__ballot(iB != 0) == 0);
+            group_front(nullptr, shB, nkB + (uint32_t)k - 1, nkB, 0u, clB, gB, badB, false, cB, iB);
             kid_u4 hB0 = issue_header(gB, 0), hB1 = issue_header(gB, 1);
             KID_TICK(3);
 
@@ -1048,7 +1046,6 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                 if (qn) resolve_all(i + 1u);
                 flush_results(i + 2u - 64u, 64u);
             }
-            __builtin_amdgcn_wave_barrier(); // the strips are rewritten by the next pair
         }
         if (qn) resolve_all(cnt - 1u);
         if (cnt & 63u) flush_results(cnt & ~63u, cnt & 63u);

@@ -5,7 +5,7 @@ TAG=$1; LIB=$2; shift 2
 OUT=$R/gpurun_out/pmcq_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export KMER_ID_AMD_LIB=$R/$LIB
-B="python3 $R/bench.py --steps 3 --warmup 1 --cpu-reads 0 --gather 0 --xcheck 0 $*"
+B="python3 $R/bench.py --steps 4 --warmup 1 --cpu-reads 0 --gather 0 --xcheck 0 $*"
 timeout -k 10 240 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY --output-format csv -d $OUT/sq_a -- $B > $OUT/sq_a.log 2>&1
 timeout -k 10 240 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq_b -- $B > $OUT/sq_b.log 2>&1
 python3 $R/tools/pmc_summary.py $OUT > $OUT/summary.json
