@@ -1008,39 +1008,39 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             const uint32_t shB = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)(ia + 1u)) & 15u;
             KidGroup<U> gA, gB;
             uint32_t badA = 0, badB = 0;
+            // the next descriptor block, if the next pair is not in this one (this pair's are in scalars by now)
+            if (ia + 3u > 63u) { blk = i + 2u; load_block(); }
 
+            // The packed words of the next pair are requested as soon as this pair's are used up, a whole
+            // trip ahead: they come from HBM (the packed image of a batch is larger than the L2).
             asm volatile("s_waitcnt vmcnt(2)" : "+v"(cA), "+v"(iA) : : "memory"); // behind: the words of B
             KID_TICK(0);
             const bool clA = (__ballot(iA != 0) == 0); // no base of the read resets a window
             group_front(nullptr, shA, nkA + (uint32_t)k - 1, nkA, 0u, clA, gA, badA, false, cA, iA);
             kid_u4 hA0 = issue_header(gA, 0), hA1 = issue_header(gA, 1);
+            issue_words(i + 2u - blk, cA, iA);
             KID_TICK(1);
 
-            asm volatile("s_waitcnt vmcnt(2)" : "+v"(cB), "+v"(iB) : : "memory"); // behind: the headers of A
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(cB), "+v"(iB) : : "memory"); // behind: headers of A, next words of A
             KID_TICK(2);
             const bool clB = (__ballot(iB != 0) == 0);
             group_front(nullptr, shB, nkB + (uint32_t)k - 1, nkB, 0u, clB, gB, badB, false, cB, iB);
             kid_u4 hB0 = issue_header(gB, 0), hB1 = issue_header(gB, 1);
+            issue_words(i + 3u - blk, cB, iB);
             KID_TICK(3);
 
-            asm volatile("s_waitcnt vmcnt(2)" : "+v"(hA0), "+v"(hA1) : : "memory"); // behind: the headers of B
+            asm volatile("s_waitcnt vmcnt(6)" : "+v"(hA0), "+v"(hA1) : : "memory"); // behind: next words of A, headers and next words of B
             KID_TICK(4);
             gA.hd[0] = make_uint4(hA0.x, hA0.y, hA0.z, hA0.w);
             gA.hd[1] = make_uint4(hA1.x, hA1.y, hA1.z, hA1.w);
             back_deferred(gA, i, true, nkA - badA);
             KID_TICK(5);
 
-            // the packed words of the next pair are requested as late as their registers allow (from the
-            // next descriptor block if need be): A's behind A's back half, B's behind B's
-            if (ia + 3u > 63u) { blk = i + 2u; load_block(); }
-            issue_words(i + 2u - blk, cA, iA);
-
-            asm volatile("s_waitcnt vmcnt(2)" : "+v"(hB0), "+v"(hB1) : : "memory"); // behind: the next words of A
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(hB0), "+v"(hB1) : : "memory"); // behind: the next words of B
             KID_TICK(6);
             gB.hd[0] = make_uint4(hB0.x, hB0.y, hB0.z, hB0.w);
             gB.hd[1] = make_uint4(hB1.x, hB1.y, hB1.z, hB1.w);
             back_deferred(gB, i + 1u, i + 1u < cnt, nkB - badB);
-            issue_words(i + 3u - blk, cB, iB);
             KID_TICK(7);
             if (((i + 2u) & 63u) == 0u) { // tags and result slots are read numbers mod 64
                 if (qn) resolve_all(i + 1u);
