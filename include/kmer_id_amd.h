@@ -115,7 +115,8 @@ void kid_sample_destroy(kid_sample *s);
  *   out_final_targ  nullable; receives process_read's return value per read
  * Side effects on the sample: gcount[final_targ]++ per read (:613), and every
  * k-mer hit with target > 1 marks its table cell as seen (:596-603).
- * Reads are independent; results do not depend on batch boundaries.            */
+ * Reads are independent; results do not depend on batch boundaries.  A batch
+ * holds at most 2^31-1 reads (KID_ERR_ARG beyond; split the batch).           */
 int kid_classify_batch(kid_sample *s, const uint8_t *bases, const uint64_t *offsets,
                        const int32_t *start, const int32_t *stop, uint64_t n_reads,
                        uint32_t *out_final_targ);
@@ -143,9 +144,10 @@ int kid_sample_end(kid_sample *s, int64_t *gcount, int64_t *ucount);
 /* {reads, k-mer lookups, table cells read, k-mer hits} so far (synchronises) */
 int kid_sample_stats(kid_sample *s, uint64_t out[4]);
 
-/* Kernel timing for benchmarks: when enabled, every batch records a HIP event pair around the
- * kid_classify_kernel launch (on the launch stream).  kid_sample_kernel_time synchronises, adds up
- * the elapsed times of the launches since the last call and returns their number.              */
+/* Kernel timing for benchmarks: when enabled, every batch records HIP event pairs around its
+ * kid_classify_kernel launches (on the launch stream; each launch between its own pair, so gaps
+ * between launches do not count).  kid_sample_kernel_time synchronises, adds up the elapsed times
+ * since the last call and returns the number of batches they belong to.                        */
 int kid_sample_set_timing(kid_sample *s, int enabled);
 int kid_sample_kernel_time(kid_sample *s, double *total_ms, uint64_t *launches);
 

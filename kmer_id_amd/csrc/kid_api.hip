@@ -56,6 +56,7 @@ struct kid_sample {
     hipStream_t stream = nullptr;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed; // around each classify launch, while timing is on
+    uint64_t timed_batches = 0;
     // per-batch scratch of the device pipeline (prepare -> pack -> classify), grown on demand
     KidRareArgs *d_rare = nullptr; // device copy, written once in kid_sample_begin (batch_max: by every batch)
     uint32_t batch_seq = 0;
@@ -495,9 +496,10 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
     return KID_OK;
 }
 
-// One batch = three launches on `stream`: kid_prepare_kernel (read descriptors + range checks),
-// kid_pack_kernel (ASCII -> 2 bit + invalid mask over the whole buffer, every lane busy) and
-// kid_classify_kernel (512-thread workgroups = 8 waves, persistent over the reads; the gcount
+// One batch = four launches on `stream`: kid_prepare_kernel (read descriptors, range checks, longest
+// read), kid_pack_kernel (ASCII -> 2 bit + invalid mask over the whole buffer, every lane busy) and the
+// two instantiations of kid_classify_kernel (512-thread workgroups = 8 waves, persistent over the
+// reads; pair loop / general loops -- the one the batch is not for returns at once; the gcount
 // histogram lives in LDS when 4 workgroups per CU still fit).
 static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_nbytes, hipStream_t stream)
 {
@@ -564,6 +566,15 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
         else if (rows) KID_LAUNCH_PK(true, false);
         else if (hist_pair) KID_LAUNCH_PK(false, true);
         else KID_LAUNCH_PK(false, false);
+        if (s->timing) { // each of the two kernels between its own pair of events: the gap between them is not kernel time
+            hipEvent_t evm0 = nullptr, evm1 = nullptr;
+            KID_HIP(hipEventCreate(&evm0));
+            KID_HIP(hipEventCreate(&evm1));
+            KID_HIP(hipEventRecord(evm0, stream));
+            s->timed.emplace_back(ev0, evm0);
+            KID_HIP(hipEventRecord(evm1, stream));
+            ev0 = evm1;
+        }
     }
     if (rows && hist && ml) KID_LAUNCH(true, true, true);
     else if (rows && hist) KID_LAUNCH(true, true, false);
@@ -579,6 +590,7 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     if (s->timing) {
         KID_HIP(hipEventRecord(ev1, stream));
         s->timed.emplace_back(ev0, ev1);
+        s->timed_batches++;
     }
     KID_HIP(hipGetLastError());
     return KID_OK;
@@ -606,8 +618,9 @@ extern "C" int kid_sample_kernel_time(kid_sample *s, double *total_ms, uint64_t 
         hipEventDestroy(ev.second);
     }
     *total_ms = sum;
-    *launches = s->timed.size();
+    *launches = s->timed_batches; // batches: the kernels of one batch count as one launch
     s->timed.clear();
+    s->timed_batches = 0;
     return KID_OK;
 }
 

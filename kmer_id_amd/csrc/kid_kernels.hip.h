@@ -307,11 +307,19 @@ __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, u
         desc[r] = d;
         if (d.n_kmers > 0 && (uint32_t)d.n_kmers > mx) mx = (uint32_t)d.n_kmers;
     }
-    // largest read of the batch, tagged with the batch number so that the word never needs a reset
+    // largest read of the batch, tagged with the batch number so that the word never needs a reset: one
+    // atomic per workgroup at most (none once a workgroup sees a value as large as its own; a batch of
+    // equal reads is announced by workgroup 0 alone)
+    __shared__ uint32_t s_mx;
+    if (threadIdx.x == 0) s_mx = 0;
+    __syncthreads();
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)mx, o); mx = y > mx ? y : mx; }
-    if ((threadIdx.x & 63u) == 0) { // one atomic for the first wave to see a new maximum, a plain load for the others
-        const unsigned long long v = ((unsigned long long)seq << 32) | mx;
+    if ((threadIdx.x & 63u) == 0 && mx) atomicMax(&s_mx, mx);
+    __syncthreads();
+    const bool uniform_batch = !b.offsets && !b.start && !b.stop;
+    if (threadIdx.x == 0 && (!uniform_batch || blockIdx.x == 0)) {
+        const unsigned long long v = ((unsigned long long)seq << 32) | s_mx;
         if (v > *reinterpret_cast<volatile unsigned long long *>(&rare->batch_max)) atomicMax(&rare->batch_max, v);
     }
     if (bad) atomicAdd(&stats[4], (unsigned long long)bad);
