@@ -576,3 +576,85 @@ def test_other_kmer_lengths(k):
     assert np.array_equal(g, eg) and np.array_equal(u, eu)
     assert s.stats()["lookups"] == os_.stats()["lookups"] and (exp > 1).sum() > n // 5
     s.close(); db.close()
+
+
+# ------------------------------------------------------------------ the pair kernel's lookup queue under load
+def _genome_db(parent, n_genomes, genome_len, rng):
+    """k-mers of random genomes; the targets of one genome walk up and down one lineage (so the msca
+    fold has work) with a few k-mers of a foreign lineage in between (so it also meets real LCAs)."""
+    depth = np.zeros(parent.size, np.int64)
+    for t in range(2, parent.size):
+        d, x = 0, t
+        while x > 1 and d < 64:
+            x = int(parent[x]); d += 1
+        depth[t] = d
+    leaves = np.flatnonzero(depth >= 3)
+    code = np.zeros(256, np.int64)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+    genomes, keys, targets = [], [], []
+    for g in range(n_genomes):
+        seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), genome_len)
+        genomes.append(seq)
+        c = code[seq]
+        nwin = genome_len - K + 1
+        key = np.zeros(nwin, np.uint64)
+        for j in range(K):
+            key = (key << np.uint64(2)) | c[j:j + nwin].astype(np.uint64)
+        t0 = int(rng.choice(leaves))
+        lineage = [t0, int(parent[t0]), int(parent[int(parent[t0])])]
+        tg = np.array(lineage, np.uint32)[rng.integers(0, 3, nwin)]
+        foreign = rng.random(nwin) < 0.02
+        tg[foreign] = rng.choice(leaves, int(foreign.sum())).astype(np.uint32)
+        keys.append(key); targets.append(tg)
+    return genomes, np.concatenate(keys), np.concatenate(targets)
+
+
+@pytest.mark.parametrize("read_len", [150, 157, 100])
+def test_dense_hits_through_the_lookup_queue(read_len):
+    """Reads cut from genomes whose every k-mer is in the DB: up to 128 queued lookups per read, runs
+    of one read split over resolver chunks, more than 64 reads per wave (tags wrap), both strands,
+    mutated copies with fewer hits, masked bases and reads without any hit in between."""
+    parent, _ = synth.load_taxonomy("bact10")
+    rng = np.random.default_rng(77 + read_len)
+    genomes, keys, targets = _genome_db(parent, 120, 2500, rng)
+    odb = oracle_db(parent, keys, targets, 21)
+    db = KmerDB(keys, targets, parent, k=K, log2_slots=21)
+    n = 560_000 if read_len == 150 else 60_000
+    comp = np.zeros(256, np.uint8)
+    for a, b_ in zip(b"ACGTN", b"TGCAN"):
+        comp[a] = b_
+    bases = np.empty(n * read_len, np.uint8)
+    kind = rng.integers(0, 4, n)
+    gi = rng.integers(0, len(genomes), n)
+    pos = rng.integers(0, 2500 - read_len + 1, n)
+    strand = rng.integers(0, 2, n)
+    for r in range(n):
+        if kind[r] == 3:
+            continue
+        s = genomes[gi[r]][pos[r]:pos[r] + read_len]
+        bases[r * read_len:(r + 1) * read_len] = comp[s[::-1]] if strand[r] else s
+    rnd = np.flatnonzero(kind == 3)
+    view = bases.reshape(n, read_len)
+    view[rnd] = rng.choice(np.frombuffer(b"ACGT", np.uint8), (rnd.size, read_len))
+    mut = np.flatnonzero(kind == 1)   # a substitution every ~25 bases: scattered hits
+    m = rng.random((mut.size, read_len)) < 0.04
+    sub = view[mut]
+    sub[m] = rng.choice(np.frombuffer(b"ACGT", np.uint8), int(m.sum()))
+    view[mut] = sub
+    masked = np.flatnonzero(kind == 2)[::3]  # an N somewhere: two runs of hits
+    view[masked, rng.integers(0, read_len, masked.size)] = ord("N")
+    off = synth.fixed_offsets(n, read_len)
+    os_ = ob.OracleSample(odb)
+    exp = os_.classify(bases, off)
+    eg, eu = os_.counts()
+    s = db.sample()
+    got = s.classify(bases, off)
+    assert np.array_equal(got, exp)
+    g, u = s.end()
+    assert np.array_equal(g, eg) and np.array_equal(u, eu)
+    st, est = s.stats(), os_.stats()
+    assert st["lookups"] == est["lookups"] and st["hits"] == est["hits"]
+    assert st["hits"] > 20 * n  # dense
+    s.close()
+    db.close()
