@@ -506,6 +506,7 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     kid_db *db = s->db;
     if (b.n == 0) return KID_OK;
     if (b.n > 0x7FFFFFFFull) return kid_fail(KID_ERR_ARG, "at most 2^31-1 reads per batch");
+    if (bases_nbytes >> 48) return kid_fail(KID_ERR_ARG, "a batch of 2^48 bytes or more");
     const uint64_t nchunks = (bases_nbytes + 15) / 16;
     if (b.n > s->sc_desc_cap) {
         if (s->sc_desc) hipFree(s->sc_desc);

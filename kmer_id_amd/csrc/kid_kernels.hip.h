@@ -802,20 +802,21 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         const uint32_t gw32 = (uint32_t)gw, nw32 = (uint32_t)nw;
         const uint32_t cnt = gw < b.n ? (uint32_t)((b.n - gw + nw - 1) / nw) : 0u; // reads of this wave: gw + i nw
         const uint32_t lane4 = lane * 4u;
-        // descriptors, 64 at a time: lane l holds the one of read number blk + l of this wave
-        uint32_t blk = 0, dv_lo = 0, dv_hi = 0, dv_nk = 0;
+        // descriptors, 64 at a time: lane l holds the one of read number blk + l of this wave -- the low word
+        // of first_base, and its high word (< 2^16: a batch is smaller than 2^48 bytes) with n_kmers (<= 128
+        // in this kernel) above it
+        uint32_t blk = 0, dv_lo = 0, dv_hn = 0;
         auto load_block = [&]() {
             const uint64_t rr = gw + (uint64_t)(blk + lane) * nw;
-            dv_lo = 0; dv_hi = 0; dv_nk = 0;
+            dv_lo = 0; dv_hn = 0;
             if (rr < b.n) {
                 const KidReadDesc d = b.desc[rr];
                 dv_lo = (uint32_t)d.first_base;
-                dv_hi = (uint32_t)(d.first_base >> 32);
-                dv_nk = d.n_kmers > 0 ? (uint32_t)d.n_kmers : 0u;
+                dv_hn = ((uint32_t)(d.first_base >> 32) & 0xFFFFu) | ((d.n_kmers > 0 ? (uint32_t)d.n_kmers : 0u) << 16);
             }
         };
         auto issue_words = [&](const uint32_t idx, uint32_t &c, uint32_t &iv) {
-            const uint64_t w0 = (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dv_hi, (int)idx) << 32) |
+            const uint64_t w0 = (((uint64_t)((uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)idx) & 0xFFFFu) << 32) |
                                  (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)idx)) >> 4;
             const uint32_t *const pc = b.codes + w0;
             const uint16_t *const pi = b.inval + w0;
@@ -930,6 +931,44 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                     }
                 }
                 if (cur_tag != 0xFFFFFFFFu && (uint32_t)__builtin_amdgcn_readfirstlane((int)tag) != cur_tag) commit_tag(cur_tag, final_t);
+                if (__popcll(hm) <= 6) {
+                    // Few, long runs (reads with many hits): the runs in turn, all entries of a run at once.
+                    // Every lane works out the step its own entry would make from the run's current result;
+                    // entries up to the first one that changes the result leave it as it is -- which is all
+                    // the sequential fold would have done with them -- so the run jumps there and repeats.
+                    // One round per change of the result, a handful per read, instead of one per hit.
+                    uint64_t runs = hm;
+                    while (runs) {
+                        const int h = __builtin_ctzll(runs);
+                        runs &= runs - 1;
+                        const uint32_t e = runs ? (uint32_t)__builtin_ctzll(runs) : n; // the run is [h, e)
+                        uint32_t uf = (uint32_t)__builtin_amdgcn_readlane((int)f, h);
+                        uint4 ufr;
+                        ufr.x = (uint32_t)__builtin_amdgcn_readlane((int)fr.x, h);
+                        ufr.y = (uint32_t)__builtin_amdgcn_readlane((int)fr.y, h);
+                        ufr.z = (uint32_t)__builtin_amdgcn_readlane((int)fr.z, h);
+                        ufr.w = (uint32_t)__builtin_amdgcn_readlane((int)fr.w, h);
+                        uint64_t rem = hitm & (e >= 64u ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << h) - 1ull);
+                        while (rem) {
+                            uint32_t rj = tgt;
+                            uint4 roj = row;
+                            if (uf != 0 && tgt != uf) { // (first hit: :592-595; msca(x,x) = x)
+                                if (ROWS) rj = kid_msca_rows(tgt, row, uf, ufr, roj);
+                                else rj = kid_msca_climb(db, tgt > 0 ? tgt : uf, uf);
+                            }
+                            const uint64_t ch = __ballot(rj != uf) & rem;
+                            if (!ch) break;
+                            const int j = __builtin_ctzll(ch);
+                            uf = (uint32_t)__builtin_amdgcn_readlane((int)rj, j);
+                            ufr.x = (uint32_t)__builtin_amdgcn_readlane((int)roj.x, j);
+                            ufr.y = (uint32_t)__builtin_amdgcn_readlane((int)roj.y, j);
+                            ufr.z = (uint32_t)__builtin_amdgcn_readlane((int)roj.z, j);
+                            ufr.w = (uint32_t)__builtin_amdgcn_readlane((int)roj.w, j);
+                            rem &= j >= 63 ? 0ull : ~((2ull << j) - 1ull);
+                        }
+                        if (lane == (uint32_t)h) { f = uf; fr = ufr; }
+                    }
+                } else
                 for (uint32_t t = 0; __ballot(head && t < len) != 0; t++) {
                     const int src = (int)(((lane + t) & 63u) << 2);
                     const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)tgt);
@@ -1010,8 +1049,8 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         issue_words(1u, cB, iB);
         for (uint32_t i = 0; i < cnt; i += 2) {
             const uint32_t ia = i - blk;
-            const uint32_t nkA = (uint32_t)__builtin_amdgcn_readlane((int)dv_nk, (int)ia);
-            const uint32_t nkB = (uint32_t)__builtin_amdgcn_readlane((int)dv_nk, (int)(ia + 1u));
+            const uint32_t nkA = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)ia) >> 16;
+            const uint32_t nkB = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)(ia + 1u)) >> 16;
             const uint32_t shA = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)ia) & 15u;
             const uint32_t shB = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)(ia + 1u)) & 15u;
             KidGroup<U> gA, gB;
