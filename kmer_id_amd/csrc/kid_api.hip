@@ -531,12 +531,16 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     const int block = 512, wpb = block / 64;
     const uint32_t ntar = (uint32_t)db->info.ntar;
     // the gcount histogram lives in LDS while four workgroups per CU (160 KiB) still fit beside the waves' strips
-    const uint32_t hist_words = (ntar + 3u) & ~3u;
-    const bool hist = (hist_words + wpb * KID_WAVE_LDS_WORDS) * 4u <= 40u * 1024u;
-    // (pair kernel: two 16-bit counters per word, so a workgroup must stay below 65536 reads per launch)
-    const uint32_t hist_words_pair = ((ntar + 1u) / 2u + 3u) & ~3u;
+    // and queues.  Minimizer-localised table: two 16-bit counters per word, so a workgroup must stay below 65536
+    // reads per launch.
+    const bool ml = db->d.minloc != 0;
     const int grid = kid_grid_for(b.n, wpb, db->num_cu * 4);
-    const bool hist_pair = (hist_words_pair + wpb * KID_PAIR_LDS_WORDS) * 4u <= 40u * 1024u && b.n / (uint64_t)grid + wpb < 65536u;
+    const bool fits16 = b.n / (uint64_t)grid + wpb < 65536u;
+    const uint32_t hist_words32 = (ntar + 3u) & ~3u, hist_words16 = ((ntar + 1u) / 2u + 3u) & ~3u;
+    const uint32_t hist_words = ml ? hist_words16 : hist_words32;
+    const uint32_t wave_words = ml ? KID_GEN_ML_LDS_WORDS : KID_WAVE_LDS_WORDS;
+    const bool hist = (hist_words + wpb * wave_words) * 4u <= 40u * 1024u && (!ml || fits16);
+    const bool hist_pair = (hist_words16 + wpb * KID_PAIR_LDS_WORDS) * 4u <= 40u * 1024u && fits16;
     KidSampleDev sd{s->gcount, s->seen, s->stats};
     const bool rows = db->rows != nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -547,9 +551,9 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     }
 #define KID_LAUNCH1(R, H, M, KF, PK)                                                                                            \
     hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, KF, PK>), dim3(grid), dim3(block),                                     \
-                       (((H) ? ((PK) ? hist_words_pair : hist_words) : 0u) +                                                    \
-                        (size_t)wpb * ((PK) ? KID_PAIR_LDS_WORDS : KID_WAVE_LDS_WORDS)) * 4, stream,                           \
-                       db->d, pk, sd, (H) ? ((PK) ? hist_words_pair : hist_words) : 0u, pk.desc, s->d_rare)
+                       (((H) ? ((PK) ? hist_words16 : hist_words) : 0u) +                                                       \
+                        (size_t)wpb * ((PK) ? KID_PAIR_LDS_WORDS : wave_words)) * 4, stream,                                   \
+                       db->d, pk, sd, (H) ? ((PK) ? hist_words16 : hist_words) : 0u, pk.desc, s->d_rare)
 #define KID_LAUNCH(R, H, M)                                                                                                    \
     do {                                                                                                                       \
         if (db->info.k == 30) KID_LAUNCH1(R, H, M, 30, false);                                                                 \
@@ -561,7 +565,6 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
         if (db->info.k == 30) KID_LAUNCH1(R, H, true, 30, true);                                                               \
         else KID_LAUNCH1(R, H, true, 0, true);                                                                                 \
     } while (0)
-    const bool ml = db->d.minloc != 0;
     if (ml && KID_PAIRS) {
         if (rows && hist_pair) KID_LAUNCH_PK(true, true);
         else if (rows) KID_LAUNCH_PK(true, false);

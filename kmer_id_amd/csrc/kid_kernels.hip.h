@@ -24,6 +24,7 @@
 #define KID_CQ_CAP 192   // a read appends at most 128 entries to fewer than KID_CQ_FLUSH queued ones
 #define KID_CQ_FLUSH 64
 #define KID_PAIR_LDS_WORDS (4 + 3 * KID_CQ_CAP + KID_CQ_CAP / 4 + 64)
+#define KID_GEN_ML_LDS_WORDS (104 + 3 * KID_CQ_CAP + KID_CQ_CAP / 4 + 64) // general loops on the minimizer-localised table: strip, counters, queue, results
 #if defined(KID_ABLATE) && KID_ABLATE >= 2
 #define KID_ABLATE_NOMIN 1
 #else
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform
     const uint32_t wpb = blockDim.x >> 6;
     uint32_t *hist = kid_smem;
-    uint32_t *WA = kid_smem + hist_words + wib * (PAIRK ? KID_PAIR_LDS_WORDS : KID_WAVE_LDS_WORDS); // strip: 66 packed words + 34 mask words
+    uint32_t *WA = kid_smem + hist_words + wib * (PAIRK ? KID_PAIR_LDS_WORDS : MINLOC ? KID_GEN_ML_LDS_WORDS : KID_WAVE_LDS_WORDS); // strip: 66 packed words + 34 mask words
 
     if (HIST) {
         for (uint32_t i = threadIdx.x; i < hist_words; i += blockDim.x) hist[i] = 0;
@@ -691,12 +692,242 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         if (lane == 0 && b.out_final) kid_store_u32_nowait(&b.out_final[r], final_t);
     };
 
+    // ==== minimizer-localised table: the back half is deferred (both kernels) =======================
+    // ---- back half, deferred.  A lookup whose header shows a fingerprint match (or a chained line)
+    // is not followed up on the spot -- that would put two more dependent round trips (hit cell,
+    // ancestor row) on every second read -- but queued in LDS; queued lookups are resolved 64 at a
+    // time, one per lane, and folded read by read (entries are in read order, then window order).
+    uint32_t *const CQ_klo = WA + (PAIRK ? 4 : 104), *const CQ_khi = CQ_klo + KID_CQ_CAP, *const CQ_lw = CQ_khi + KID_CQ_CAP;
+    uint8_t *const CQ_tag = reinterpret_cast<uint8_t *>(CQ_lw + KID_CQ_CAP); // read number mod 64
+    // per-read results wait in LDS for one scattered store per 64 reads: a pending store shares vmcnt
+    // with the loads, and the explicit counts of the loop would have to sit out its acknowledgement
+    uint32_t *const RB = CQ_lw + KID_CQ_CAP + KID_CQ_CAP / 4;
+    const uint32_t gw32 = (uint32_t)gw, nw32 = (uint32_t)nw; // 32-bit read indices (n < 2^31): read number i of this wave is gw + i nw
+    uint64_t rb_skip = 0;   // result slots of the current block of 64 reads that are not this pass's to store
+    bool rb_direct = false; // second pass of the general loops (reads of more than one segment): results stored at once
+    auto flush_results = [&](const uint32_t i0, const uint32_t n) { // this wave's reads i0 .. i0+n-1 (n <= 64)
+        if (b.out_final && lane < n && !((rb_skip >> ((i0 + lane) & 63u)) & 1ull))
+            kid_store_u32_nowait(&b.out_final[gw32 + (i0 + lane) * nw32], RB[(i0 + lane) & 63u]);
+        rb_skip = 0;
+    };
+    uint32_t qn = 0;        // wave-uniform fill of the queue
+    uint32_t n_lookups = 0; // wave-uniform; per wave and launch: stays below 2^32 for batches of < 2^31 reads x 128 k-mers (longer reads: mod 2^32 is accepted for this counter)
+    // the read the resolver left open (its run ended a chunk, or it is still being classified), and its fold so far
+    uint32_t cur_tag = 0xFFFFFFFFu, final_c = 0, vfrow_c = 0;
+    auto commit = [&](const uint32_t i, const uint32_t final_t) { // gcount[final]++ (:605), per-read output
+        if (HIST) {
+            if (lane == 0) atomicAdd(&hist[final_t >> 1], 1u << (16u * (final_t & 1u)));
+        } else if (final_t == pend_t) {
+            pend_n++;
+        } else {
+            if (pend_n && lane == 0) atomicAdd(&rare->gcount[pend_t], (unsigned long long)pend_n);
+            pend_t = final_t;
+            pend_n = 1;
+        }
+        if (rb_direct) { if (lane == 0 && b.out_final) kid_store_u32_nowait(&b.out_final[gw32 + i * nw32], final_t); }
+        else if (lane == 0) RB[i & 63u] = final_t;
+    };
+    // i_now: number of the newest queued read (all are within 63 of it); open_tag: a read that may still get
+    // entries (general loops, between the groups of a read) -- its run is folded but not committed
+    auto resolve_all = [&](const uint32_t i_now, const uint32_t open_tag) {
+#ifdef KID_PROFILE
+        const unsigned long long rt0 = __builtin_amdgcn_s_memtime();
+#endif
+        // (the pair kernel never leaves a read open between calls: its carry lives and dies in here)
+        uint32_t ctag = PAIRK ? 0xFFFFFFFFu : cur_tag, final_t = PAIRK ? 0u : final_c, vfrow = PAIRK ? 0u : vfrow_c;
+        auto commit_tag = [&](const uint32_t tag, const uint32_t f) {
+            commit(i_now - ((i_now - tag) & 63u), f);
+        };
+        for (uint32_t base = 0; base < qn; base += 64u) {
+            const uint32_t n = qn - base < 64u ? qn - base : 64u;
+            const bool valid = lane < n;
+            uint32_t klo = 0, khi = 0, ln = 0, tag = 0;
+            if (valid) { klo = CQ_klo[base + lane]; khi = CQ_khi[base + lane]; ln = CQ_lw[base + lane]; tag = CQ_tag[base + lane]; }
+            // the header once more (the queue keeps only the line: working out the candidates at
+            // queueing time would cost the hot loop ~45 instructions per read with a match)
+            uint32_t tgt = 0, slot = 0, mu = 0;
+            const uint32_t fp = kid_key_fp(((uint64_t)khi << 32) | klo);
+            bool fu = false;
+            if (valid) {
+                const uint4 h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
+                mu = kid_hdr_cand(h, fp);
+                fu = (h.w >> 16) >= KID_HDR_FULL;
+            }
+            { // (cells read: one add for the wave, not one per lane on the same LDS word)
+                const uint64_t cm = __ballot(mu != 0);
+                if (cm && lane == 0) atomicAdd(&WC[3], (uint32_t)__popcll(cm));
+            }
+            if (mu) { // the first candidate of every entry in one round trip: almost always the key itself
+                const uint32_t idx = ln * KID_LINE_CELLS + 1u + kid_cand_entry((uint32_t)__builtin_ctz(mu));
+                mu &= mu - 1;
+                const uint4 c = kid_load_cell(db.table, idx);
+                if (c.z != 0 && c.x == klo && c.y == khi) { tgt = c.z; slot = idx; }
+            }
+            bool go = valid && tgt == 0 && (mu != 0 || fu);
+            while (go) { // a second candidate (1e-4 of the lookups) or a chained line (1e-5)
+                if (mu) {
+                    const uint32_t j = kid_cand_entry((uint32_t)__builtin_ctz(mu));
+                    mu &= mu - 1;
+                    const uint32_t ix = ln * KID_LINE_CELLS + 1u + j;
+                    const uint4 cc = kid_load_cell(db.table, ix);
+                    atomicAdd(&WC[3], 1u);
+                    if (cc.z != 0 && cc.x == klo && cc.y == khi) { tgt = cc.z; slot = ix; go = false; }
+                } else if (fu) {
+                    ln = (ln + 1u) & rare->line_mask;
+                    const uint4 h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
+                    atomicAdd(&WC[3], 1u);
+                    mu = kid_hdr_cand(h, fp);
+                    fu = (h.w >> 16) >= KID_HDR_FULL;
+                } else go = false;
+            }
+            uint4 row = make_uint4(0, 0, 0, 0);
+            if (tgt > 0) {
+                if (ROWS) row = db.rows[tgt];
+                if (tgt > 1) kid_atomic_or_nowait(&s.seen[slot >> 5], 1u << (slot & 31u));
+            }
+            const uint64_t hitm = __ballot(tgt > 0);
+            if (hitm && lane == 0) atomicAdd(&WC[2], (uint32_t)__popcll(hitm));
+            // Fold read by read, one lane per read: entries of a read are neighbours (a change of tag
+            // starts the next read); the first lane of a run walks its run in window order, fetching
+            // (target, ancestor row) of entry lane + t with ds_bpermute.  The left fold of msca over
+            // the hits of a read, newkmer_10nx.cpp:588-595.
+            const uint32_t tprev = (uint32_t)__shfl_up((int)tag, 1);
+            const bool head = valid && (lane == 0 || tag != tprev);
+            const uint64_t hm = __ballot(head);
+            const uint64_t above = lane < 63u ? (hm >> (lane + 1u)) : 0ull;
+            const uint32_t len = above ? (uint32_t)__builtin_ctzll(above) + 1u : n - lane; // entries of this run (head lanes)
+            uint32_t f = 0;
+            uint4 fr = make_uint4(0, 0, 0, 0);
+            if (lane == 0 && ctag != 0xFFFFFFFFu) {
+                if (valid && tag == ctag) { // the run continues the read left open by the chunk before
+                    f = final_t;
+                    fr.x = (uint32_t)__builtin_amdgcn_readlane((int)vfrow, 0);
+                    fr.y = (uint32_t)__builtin_amdgcn_readlane((int)vfrow, 1);
+                    fr.z = (uint32_t)__builtin_amdgcn_readlane((int)vfrow, 2);
+                    fr.w = (uint32_t)__builtin_amdgcn_readlane((int)vfrow, 3);
+                }
+            }
+            if (ctag != 0xFFFFFFFFu && (uint32_t)__builtin_amdgcn_readfirstlane((int)tag) != ctag) commit_tag(ctag, final_t);
+            if (__popcll(hm) <= 6) {
+                // Few, long runs (reads with many hits): the runs in turn, all entries of a run at once.
+                // Every lane works out the step its own entry would make from the run's current result;
+                // entries up to the first one that changes the result leave it as it is -- which is all
+                // the sequential fold would have done with them -- so the run jumps there and repeats.
+                // One round per change of the result, a handful per read, instead of one per hit.
+                uint64_t runs = hm;
+                while (runs) {
+                    const int h = __builtin_ctzll(runs);
+                    runs &= runs - 1;
+                    const uint32_t e = runs ? (uint32_t)__builtin_ctzll(runs) : n; // the run is [h, e)
+                    uint32_t uf = (uint32_t)__builtin_amdgcn_readlane((int)f, h);
+                    uint4 ufr;
+                    ufr.x = (uint32_t)__builtin_amdgcn_readlane((int)fr.x, h);
+                    ufr.y = (uint32_t)__builtin_amdgcn_readlane((int)fr.y, h);
+                    ufr.z = (uint32_t)__builtin_amdgcn_readlane((int)fr.z, h);
+                    ufr.w = (uint32_t)__builtin_amdgcn_readlane((int)fr.w, h);
+                    uint64_t rem = hitm & (e >= 64u ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << h) - 1ull);
+                    while (rem) {
+                        uint32_t rj = tgt;
+                        uint4 roj = row;
+                        if (uf != 0 && tgt != uf) { // (first hit: :592-595; msca(x,x) = x)
+                            if (ROWS) rj = kid_msca_rows(tgt, row, uf, ufr, roj);
+                            else rj = kid_msca_climb(db, tgt > 0 ? tgt : uf, uf);
+                        }
+                        const uint64_t ch = __ballot(rj != uf) & rem;
+                        if (!ch) break;
+                        const int j = __builtin_ctzll(ch);
+                        uf = (uint32_t)__builtin_amdgcn_readlane((int)rj, j);
+                        ufr.x = (uint32_t)__builtin_amdgcn_readlane((int)roj.x, j);
+                        ufr.y = (uint32_t)__builtin_amdgcn_readlane((int)roj.y, j);
+                        ufr.z = (uint32_t)__builtin_amdgcn_readlane((int)roj.z, j);
+                        ufr.w = (uint32_t)__builtin_amdgcn_readlane((int)roj.w, j);
+                        rem &= j >= 63 ? 0ull : ~((2ull << j) - 1ull);
+                    }
+                    if (lane == (uint32_t)h) { f = uf; fr = ufr; }
+                }
+            } else
+            for (uint32_t t = 0; __ballot(head && t < len) != 0; t++) {
+                const int src = (int)(((lane + t) & 63u) << 2);
+                const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)tgt);
+                uint4 rx;
+                rx.x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)row.x);
+                rx.y = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)row.y);
+                rx.z = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)row.z);
+                rx.w = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)row.w);
+                if (head && t < len && x != 0 && x != f) { // msca(x,x) = x
+                    if (f != 0) {
+                        if (ROWS) {
+                            uint4 ro;
+                            f = kid_msca_rows(x, rx, f, fr, ro);
+                            fr = ro;
+                        } else {
+                            f = kid_msca_climb(db, x, f);
+                        }
+                    } else {
+                        f = x; // :592-595
+                        fr = rx;
+                    }
+                }
+            }
+            // every run but the last one is a finished read; the last one too unless a chunk follows
+            const uint32_t last = 63u - (uint32_t)__builtin_clzll(hm); // hm != 0: n >= 1
+            const bool more_chunks = base + 64u < qn || (uint32_t)__builtin_amdgcn_readlane((int)tag, (int)last) == open_tag; // "keep the last run open"
+            if (head && (lane != last || !more_chunks)) {
+                if (HIST) atomicAdd(&hist[f >> 1], 1u << (16u * (f & 1u)));
+                else atomicAdd(&rare->gcount[f], 1ull);
+                if (rb_direct) { if (b.out_final) kid_store_u32_nowait(&b.out_final[gw32 + (i_now - ((i_now - tag) & 63u)) * nw32], f); }
+                else RB[tag] = f; // tag = read number mod 64
+            }
+            if (more_chunks) {
+                ctag = (uint32_t)__builtin_amdgcn_readlane((int)tag, (int)last);
+                final_t = (uint32_t)__builtin_amdgcn_readlane((int)f, (int)last);
+                const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)fr.x, (int)last), a1 = (uint32_t)__builtin_amdgcn_readlane((int)fr.y, (int)last);
+                const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)fr.z, (int)last), a3 = (uint32_t)__builtin_amdgcn_readlane((int)fr.w, (int)last);
+                vfrow = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : lane == 3 ? a3 : vfrow;
+            } else {
+                ctag = 0xFFFFFFFFu;
+            }
+        }
+        if (ctag != 0xFFFFFFFFu && ctag != open_tag) { commit_tag(ctag, final_t); ctag = 0xFFFFFFFFu; }
+        if (!PAIRK) { cur_tag = ctag; final_c = final_t; vfrow_c = vfrow; }
+        qn = 0;
+#ifdef KID_PROFILE
+        prof[9] += __builtin_amdgcn_s_memtime() - rt0; // (also contained in the phase that called)
+#endif
+    };
+    // header test of one group of a read; its unsettled lookups go to the queue.  false: there were none
+    auto back_deferred = [&](const KidGroup<U> &g, const uint32_t i) -> bool {
+        uint32_t fp[U];
+        bool mm[U], more = false;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            fp[u] = (g.fpp >> (16 * u)) & 0xFFFFu;
+            mm[u] = g.act[u] && (kid_hdr_any(g.hd[u], fp[u]) || (g.hd[u].w >> 16) >= KID_HDR_FULL);
+            more |= mm[u];
+        }
+        if (__ballot(more) == 0) return false; // (wave-uniform) ~99 % of the lookups are settled by their header
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t qm = __ballot(mm[u]);
+            if (qm == 0) continue;
+            if (mm[u]) {
+                const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
+                CQ_klo[pos] = (uint32_t)g.key[u];
+                CQ_khi[pos] = (uint32_t)(g.key[u] >> 32);
+                CQ_lw[pos] = g.hlo[u];
+                CQ_tag[pos] = (uint8_t)(i & 63u);
+            }
+            qn += (uint32_t)__popcll(qm);
+        }
+        return true;
+    };
+
     // ---- a whole read of any length on its own, given its descriptor and its first packed segment.
     // `prefetch` issues the loads for the reads behind this one; it is called right after this read's
     // first header loads went out (not before the loops: the compiler drains vmcnt in front of a loop)
-    auto process_read = [&](const uint64_t r, const uint64_t first, const int64_t nk, const uint32_t st_codes,
+    auto process_read = [&](const uint64_t r, const uint32_t i, const uint64_t first, const int64_t nk, const uint32_t st_codes,
                             const uint32_t st_inv, auto &&prefetch) {
-        bool prefetched = false;
+        bool prefetched = false, had = false;
         uint32_t final_t = 0;
         uint32_t vfrow = 0, n_bad = 0;
         for (int64_t seg = 0; seg < nk; seg += KID_SEG_KMERS) {
@@ -719,11 +950,21 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                 KidGroup<U> g;
                 group_front(WA, sh, nb, segk, t0, seg_clean, g, n_bad);
                 if (!prefetched) { prefetch(); prefetched = true; }
-                group_back(g, final_t, vfrow);
+                if constexpr (MINLOC) {
+                    had |= back_deferred(g, i);
+                    if (qn >= KID_CQ_FLUSH) resolve_all(i, i & 63u); // the read stays open: more groups may follow
+                } else {
+                    group_back(g, final_t, vfrow);
+                }
             }
             __builtin_amdgcn_wave_barrier(); // strip is rewritten by the next segment / read
         }
-        finish_read(r, final_t, (nk > 0 ? (uint32_t)nk : 0u) - n_bad);
+        if constexpr (MINLOC) {
+            n_lookups += (nk > 0 ? (uint32_t)nk : 0u) - n_bad;
+            if (!had) commit(i, 0u); // (else the resolver commits it, now that it is closed)
+        } else {
+            finish_read(r, final_t, (nk > 0 ? (uint32_t)nk : 0u) - n_bad);
+        }
         if (!prefetched) prefetch();
     };
 
@@ -745,10 +986,10 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
     // ---- phase 1: every read of one segment (<= 960 k-mers: all short-read data).  Longer ones are
     // left to phase 2, so that their loop nest and 64-bit bookkeeping stay out of this loop's registers
     bool any_long = false;
-    auto short_read = [&](const uint32_t r, const uint64_t first, const int32_t nk, const uint32_t st_codes,
+    auto short_read = [&](const uint32_t r, const uint32_t i, const uint64_t first, const int32_t nk, const uint32_t st_codes,
                           const uint32_t st_inv, auto &&prefetch) {
-        if (nk > KID_SEG_KMERS) { any_long = true; prefetch(); return; }
-        bool prefetched = false;
+        if (nk > KID_SEG_KMERS) { any_long = true; rb_skip |= 1ull << (i & 63u); prefetch(); return; }
+        bool prefetched = false, had = false;
         uint32_t final_t = 0;
         uint32_t vfrow = 0, n_bad = 0;
         if (nk > 0) {
@@ -778,13 +1019,23 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                 KID_TICK(2); // stage + front half
                 KID_DRAIN();
                 KID_TICK(3); // waiting for the headers
-                group_back(g, final_t, vfrow);
+                if constexpr (MINLOC) {
+                    had |= back_deferred(g, i);
+                    if (qn >= KID_CQ_FLUSH) resolve_all(i, i & 63u); // the read stays open: more groups may follow
+                } else {
+                    group_back(g, final_t, vfrow);
+                }
                 KID_DRAIN();
                 KID_TICK(4); // back half incl. hit path
             }
             __builtin_amdgcn_wave_barrier(); // strip is rewritten by the next read
         }
-        finish_read(r, final_t, (nk > 0 ? (uint32_t)nk : 0u) - n_bad);
+        if constexpr (MINLOC) {
+            n_lookups += (nk > 0 ? (uint32_t)nk : 0u) - n_bad;
+            if (!had) commit(i, 0u); // (else the resolver commits it, now that it is closed)
+        } else {
+            finish_read(r, final_t, (nk > 0 ? (uint32_t)nk : 0u) - n_bad);
+        }
         if (!prefetched) prefetch();
         KID_TICK(5);
     };
@@ -799,7 +1050,6 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
     // return in order, and anything the compiler issues in between (hit cells, atomics, the out_final
     // store) only makes an explicit count stricter than needed.
     if constexpr (PAIRK) {
-        const uint32_t gw32 = (uint32_t)gw, nw32 = (uint32_t)nw;
         const uint32_t cnt = gw < b.n ? (uint32_t)((b.n - gw + nw - 1) / nw) : 0u; // reads of this wave: gw + i nw
         const uint32_t lane4 = lane * 4u;
         // descriptors, 64 at a time: lane l holds the one of read number blk + l of this wave -- the low word
@@ -832,216 +1082,6 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
 #endif
             return v;
-        };
-        // ---- back half, deferred.  A lookup whose header shows a fingerprint match (or a chained line)
-        // is not followed up on the spot -- that would put two more dependent round trips (hit cell,
-        // ancestor row) on every second read -- but queued in LDS; queued lookups are resolved 64 at a
-        // time, one per lane, and folded read by read (entries are in read order, then window order).
-        uint32_t *const CQ_klo = WA + 4, *const CQ_khi = CQ_klo + KID_CQ_CAP, *const CQ_lw = CQ_khi + KID_CQ_CAP;
-        uint8_t *const CQ_tag = reinterpret_cast<uint8_t *>(CQ_lw + KID_CQ_CAP); // read number mod 64
-        // per-read results wait in LDS for one scattered store per 64 reads: a pending store shares vmcnt
-        // with the loads, and the explicit counts of the loop would have to sit out its acknowledgement
-        uint32_t *const RB = CQ_lw + KID_CQ_CAP + KID_CQ_CAP / 4;
-        auto flush_results = [&](const uint32_t i0, const uint32_t n) { // this wave's reads i0 .. i0+n-1 (n <= 64)
-            if (b.out_final && lane < n) kid_store_u32_nowait(&b.out_final[gw32 + (i0 + lane) * nw32], RB[(i0 + lane) & 63u]);
-        };
-        uint32_t qn = 0;        // wave-uniform fill of the queue
-        uint32_t n_lookups = 0; // wave-uniform: below 2^32 per wave and launch (n < 2^31 reads of <= 128 k-mers, 8192 waves)
-        auto commit = [&](const uint32_t i, const uint32_t final_t) { // gcount[final]++ (:605), per-read output
-            if (HIST) {
-                if (lane == 0) atomicAdd(&hist[final_t >> 1], 1u << (16u * (final_t & 1u)));
-            } else if (final_t == pend_t) {
-                pend_n++;
-            } else {
-                if (pend_n && lane == 0) atomicAdd(&rare->gcount[pend_t], (unsigned long long)pend_n);
-                pend_t = final_t;
-                pend_n = 1;
-            }
-            if (lane == 0) RB[i & 63u] = final_t;
-        };
-        auto resolve_all = [&](const uint32_t i_now) { // i_now: number of the newest queued read (all are within 63 of it)
-            uint32_t cur_tag = 0xFFFFFFFFu, final_t = 0, vfrow = 0; // no read open
-            auto commit_tag = [&](const uint32_t tag, const uint32_t f) {
-                commit(i_now - ((i_now - tag) & 63u), f);
-            };
-            for (uint32_t base = 0; base < qn; base += 64u) {
-                const uint32_t n = qn - base < 64u ? qn - base : 64u;
-                const bool valid = lane < n;
-                uint32_t klo = 0, khi = 0, ln = 0, tag = 0;
-                if (valid) { klo = CQ_klo[base + lane]; khi = CQ_khi[base + lane]; ln = CQ_lw[base + lane]; tag = CQ_tag[base + lane]; }
-                // the header once more (the queue keeps only the line: working out the candidates at
-                // queueing time would cost the hot loop ~45 instructions per read with a match)
-                uint32_t tgt = 0, slot = 0, mu = 0;
-                const uint32_t fp = kid_key_fp(((uint64_t)khi << 32) | klo);
-                bool fu = false;
-                if (valid) {
-                    const uint4 h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
-                    mu = kid_hdr_cand(h, fp);
-                    fu = (h.w >> 16) >= KID_HDR_FULL;
-                }
-                if (mu) { // the first candidate of every entry in one round trip: almost always the key itself
-                    const uint32_t idx = ln * KID_LINE_CELLS + 1u + kid_cand_entry((uint32_t)__builtin_ctz(mu));
-                    mu &= mu - 1;
-                    const uint4 c = kid_load_cell(db.table, idx);
-                    atomicAdd(&WC[3], 1u);
-                    if (c.z != 0 && c.x == klo && c.y == khi) { tgt = c.z; slot = idx; }
-                }
-                bool go = valid && tgt == 0 && (mu != 0 || fu);
-                while (go) { // a second candidate (1e-4 of the lookups) or a chained line (1e-5)
-                    if (mu) {
-                        const uint32_t j = kid_cand_entry((uint32_t)__builtin_ctz(mu));
-                        mu &= mu - 1;
-                        const uint32_t ix = ln * KID_LINE_CELLS + 1u + j;
-                        const uint4 cc = kid_load_cell(db.table, ix);
-                        atomicAdd(&WC[3], 1u);
-                        if (cc.z != 0 && cc.x == klo && cc.y == khi) { tgt = cc.z; slot = ix; go = false; }
-                    } else if (fu) {
-                        ln = (ln + 1u) & rare->line_mask;
-                        const uint4 h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
-                        atomicAdd(&WC[3], 1u);
-                        mu = kid_hdr_cand(h, fp);
-                        fu = (h.w >> 16) >= KID_HDR_FULL;
-                    } else go = false;
-                }
-                uint4 row = make_uint4(0, 0, 0, 0);
-                if (tgt > 0) {
-                    if (ROWS) row = db.rows[tgt];
-                    if (tgt > 1) kid_atomic_or_nowait(&s.seen[slot >> 5], 1u << (slot & 31u));
-                }
-                const uint64_t hitm = __ballot(tgt > 0);
-                if (hitm && lane == 0) atomicAdd(&WC[2], (uint32_t)__popcll(hitm));
-                // Fold read by read, one lane per read: entries of a read are neighbours (a change of tag
-                // starts the next read); the first lane of a run walks its run in window order, fetching
-                // (target, ancestor row) of entry lane + t with ds_bpermute.  The left fold of msca over
-                // the hits of a read, newkmer_10nx.cpp:588-595.
-                const uint32_t tprev = (uint32_t)__shfl_up((int)tag, 1);
-                const bool head = valid && (lane == 0 || tag != tprev);
-                const uint64_t hm = __ballot(head);
-                const uint64_t above = lane < 63u ? (hm >> (lane + 1u)) : 0ull;
-                const uint32_t len = above ? (uint32_t)__builtin_ctzll(above) + 1u : n - lane; // entries of this run (head lanes)
-                uint32_t f = 0;
-                uint4 fr = make_uint4(0, 0, 0, 0);
-                if (lane == 0 && cur_tag != 0xFFFFFFFFu) {
-                    if (valid && tag == cur_tag) { // the run continues the read left open by the chunk before
-                        f = final_t;
-                        fr.x = (uint32_t)__builtin_amdgcn_readlane((int)vfrow, 0);
-                        fr.y = (uint32_t)__builtin_amdgcn_readlane((int)vfrow, 1);
-                        fr.z = (uint32_t)__builtin_amdgcn_readlane((int)vfrow, 2);
-                        fr.w = (uint32_t)__builtin_amdgcn_readlane((int)vfrow, 3);
-                    }
-                }
-                if (cur_tag != 0xFFFFFFFFu && (uint32_t)__builtin_amdgcn_readfirstlane((int)tag) != cur_tag) commit_tag(cur_tag, final_t);
-                if (__popcll(hm) <= 6) {
-                    // Few, long runs (reads with many hits): the runs in turn, all entries of a run at once.
-                    // Every lane works out the step its own entry would make from the run's current result;
-                    // entries up to the first one that changes the result leave it as it is -- which is all
-                    // the sequential fold would have done with them -- so the run jumps there and repeats.
-                    // One round per change of the result, a handful per read, instead of one per hit.
-                    uint64_t runs = hm;
-                    while (runs) {
-                        const int h = __builtin_ctzll(runs);
-                        runs &= runs - 1;
-                        const uint32_t e = runs ? (uint32_t)__builtin_ctzll(runs) : n; // the run is [h, e)
-                        uint32_t uf = (uint32_t)__builtin_amdgcn_readlane((int)f, h);
-                        uint4 ufr;
-                        ufr.x = (uint32_t)__builtin_amdgcn_readlane((int)fr.x, h);
-                        ufr.y = (uint32_t)__builtin_amdgcn_readlane((int)fr.y, h);
-                        ufr.z = (uint32_t)__builtin_amdgcn_readlane((int)fr.z, h);
-                        ufr.w = (uint32_t)__builtin_amdgcn_readlane((int)fr.w, h);
-                        uint64_t rem = hitm & (e >= 64u ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << h) - 1ull);
-                        while (rem) {
-                            uint32_t rj = tgt;
-                            uint4 roj = row;
-                            if (uf != 0 && tgt != uf) { // (first hit: :592-595; msca(x,x) = x)
-                                if (ROWS) rj = kid_msca_rows(tgt, row, uf, ufr, roj);
-                                else rj = kid_msca_climb(db, tgt > 0 ? tgt : uf, uf);
-                            }
-                            const uint64_t ch = __ballot(rj != uf) & rem;
-                            if (!ch) break;
-                            const int j = __builtin_ctzll(ch);
-                            uf = (uint32_t)__builtin_amdgcn_readlane((int)rj, j);
-                            ufr.x = (uint32_t)__builtin_amdgcn_readlane((int)roj.x, j);
-                            ufr.y = (uint32_t)__builtin_amdgcn_readlane((int)roj.y, j);
-                            ufr.z = (uint32_t)__builtin_amdgcn_readlane((int)roj.z, j);
-                            ufr.w = (uint32_t)__builtin_amdgcn_readlane((int)roj.w, j);
-                            rem &= j >= 63 ? 0ull : ~((2ull << j) - 1ull);
-                        }
-                        if (lane == (uint32_t)h) { f = uf; fr = ufr; }
-                    }
-                } else
-                for (uint32_t t = 0; __ballot(head && t < len) != 0; t++) {
-                    const int src = (int)(((lane + t) & 63u) << 2);
-                    const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)tgt);
-                    uint4 rx;
-                    rx.x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)row.x);
-                    rx.y = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)row.y);
-                    rx.z = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)row.z);
-                    rx.w = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)row.w);
-                    if (head && t < len && x != 0 && x != f) { // msca(x,x) = x
-                        if (f != 0) {
-                            if (ROWS) {
-                                uint4 ro;
-                                f = kid_msca_rows(x, rx, f, fr, ro);
-                                fr = ro;
-                            } else {
-                                f = kid_msca_climb(db, x, f);
-                            }
-                        } else {
-                            f = x; // :592-595
-                            fr = rx;
-                        }
-                    }
-                }
-                // every run but the last one is a finished read; the last one too unless a chunk follows
-                const uint32_t last = 63u - (uint32_t)__builtin_clzll(hm); // hm != 0: n >= 1
-                const bool more_chunks = base + 64u < qn;
-                if (head && (lane != last || !more_chunks)) {
-                    if (HIST) atomicAdd(&hist[f >> 1], 1u << (16u * (f & 1u)));
-                    else atomicAdd(&rare->gcount[f], 1ull);
-                    RB[tag] = f; // tag = read number mod 64
-                }
-                if (more_chunks) {
-                    cur_tag = (uint32_t)__builtin_amdgcn_readlane((int)tag, (int)last);
-                    final_t = (uint32_t)__builtin_amdgcn_readlane((int)f, (int)last);
-                    const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)fr.x, (int)last), a1 = (uint32_t)__builtin_amdgcn_readlane((int)fr.y, (int)last);
-                    const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)fr.z, (int)last), a3 = (uint32_t)__builtin_amdgcn_readlane((int)fr.w, (int)last);
-                    vfrow = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : lane == 3 ? a3 : vfrow;
-                } else {
-                    cur_tag = 0xFFFFFFFFu;
-                }
-            }
-            if (cur_tag != 0xFFFFFFFFu) commit_tag(cur_tag, final_t);
-            qn = 0;
-        };
-        // header test of one read; its unsettled lookups go to the queue, a read without any is done
-        auto back_deferred = [&](const KidGroup<U> &g, const uint32_t i, const bool exists, const uint32_t n_valid) {
-            if (exists) n_lookups += n_valid;
-            uint32_t fp[U];
-            bool mm[U], more = false;
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                fp[u] = (g.fpp >> (16 * u)) & 0xFFFFu;
-                mm[u] = g.act[u] && (kid_hdr_any(g.hd[u], fp[u]) || (g.hd[u].w >> 16) >= KID_HDR_FULL);
-                more |= mm[u];
-            }
-            if (__ballot(more) == 0) { // (wave-uniform) ~99 % of the lookups are settled by their header
-                if (exists) commit(i, 0u);
-                return;
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint64_t qm = __ballot(mm[u]);
-                if (qm == 0) continue;
-                if (mm[u]) {
-                    const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
-                    CQ_klo[pos] = (uint32_t)g.key[u];
-                    CQ_khi[pos] = (uint32_t)(g.key[u] >> 32);
-                    CQ_lw[pos] = g.hlo[u];
-                    CQ_tag[pos] = (uint8_t)(i & 63u);
-                }
-                qn += (uint32_t)__popcll(qm);
-            }
-            if (qn >= KID_CQ_FLUSH) resolve_all(i);
         };
         load_block();
         uint32_t cA, iA, cB, iB;
@@ -1080,23 +1120,28 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             KID_TICK(4);
             gA.hd[0] = make_uint4(hA0.x, hA0.y, hA0.z, hA0.w);
             gA.hd[1] = make_uint4(hA1.x, hA1.y, hA1.z, hA1.w);
-            back_deferred(gA, i, true, nkA - badA);
+            n_lookups += nkA - badA;
+            if (!back_deferred(gA, i)) commit(i, 0u);
+            else if (qn >= KID_CQ_FLUSH) resolve_all(i, 0xFFFFFFFFu);
             KID_TICK(5);
 
             asm volatile("s_waitcnt vmcnt(2)" : "+v"(hB0), "+v"(hB1) : : "memory"); // behind: the next words of B
             KID_TICK(6);
             gB.hd[0] = make_uint4(hB0.x, hB0.y, hB0.z, hB0.w);
             gB.hd[1] = make_uint4(hB1.x, hB1.y, hB1.z, hB1.w);
-            back_deferred(gB, i + 1u, i + 1u < cnt, nkB - badB);
+            if (i + 1u < cnt) { // (a wave with an odd number of reads: B is a phantom of zero k-mers)
+                n_lookups += nkB - badB;
+                if (!back_deferred(gB, i + 1u)) commit(i + 1u, 0u);
+                else if (qn >= KID_CQ_FLUSH) resolve_all(i + 1u, 0xFFFFFFFFu);
+            }
             KID_TICK(7);
             if (((i + 2u) & 63u) == 0u) { // tags and result slots are read numbers mod 64
-                if (qn) resolve_all(i + 1u);
+                if (qn) resolve_all(i + 1u, 0xFFFFFFFFu);
                 flush_results(i + 2u - 64u, 64u);
             }
         }
-        if (qn) resolve_all(cnt - 1u);
+        if (qn) resolve_all(cnt - 1u, 0xFFFFFFFFu);
         if (cnt & 63u) flush_results(cnt & ~63u, cnt & 63u);
-        if (lane == 0) atomicAdd(WL, (unsigned long long)n_lookups);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(cA), "+v"(iA), "+v"(cB), "+v"(iB) : : "memory");
     }
 #endif
@@ -1105,40 +1150,54 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         // copied between stages: the descriptor of a read is requested two reads ahead (scalar loads)
         // and its first packed words one read ahead; the waits the compiler places in front of their
         // first use land behind a whole read's worth of work.  32-bit read indices (n < 2^31).
-        const uint32_t n32 = (uint32_t)b.n, gw32 = (uint32_t)gw, nw32 = (uint32_t)nw;
+        const uint32_t n32 = (uint32_t)b.n;
         KidReadDesc dA, dB;
         uint32_t cA, iA, cB, iB;
         fetch_desc(gw32, dA);
         fetch_desc(gw32 + nw32, dB);
         fetch_words(dA, cA, iA);
-        for (uint32_t r = gw32; r < n32; r += 2 * nw32) {
-            short_read(r, uniform64(dA.first_base), __builtin_amdgcn_readfirstlane(dA.n_kmers), cA, iA,
+        uint32_t i = 0; // number of the read within this wave
+        for (uint32_t r = gw32; r < n32; r += 2 * nw32, i += 2) {
+            short_read(r, i, uniform64(dA.first_base), __builtin_amdgcn_readfirstlane(dA.n_kmers), cA, iA,
                        [&]() { fetch_words(dB, cB, iB); fetch_desc(r + 2 * nw32, dA); });
             if (r + nw32 >= n32) break;
-            short_read(r + nw32, uniform64(dB.first_base), __builtin_amdgcn_readfirstlane(dB.n_kmers), cB, iB,
+            short_read(r + nw32, i + 1u, uniform64(dB.first_base), __builtin_amdgcn_readfirstlane(dB.n_kmers), cB, iB,
                        [&]() { fetch_words(dA, cA, iA); fetch_desc(r + 3 * nw32, dB); });
+            if (MINLOC && ((i + 2u) & 63u) == 0u) { // tags and result slots are read numbers mod 64
+                if (qn || cur_tag != 0xFFFFFFFFu) resolve_all(i + 1u, 0xFFFFFFFFu);
+                flush_results(i + 2u - 64u, 64u);
+            }
+        }
+        if (MINLOC) {
+            const uint32_t cnt = gw < b.n ? (uint32_t)((b.n - gw + nw - 1) / nw) : 0u;
+            if (qn || cur_tag != 0xFFFFFFFFu) resolve_all(cnt - 1u, 0xFFFFFFFFu);
+            if (cnt & 63u) flush_results(cnt & ~63u, cnt & 63u);
         }
     }
     // ---- phase 2: the long reads this wave met (FASTA records, long-read data), one at a time
     if (!PAIRK && any_long) {
-        for (uint64_t r = gw; r < b.n; r += nw) {
+        rb_direct = true; // the other reads' results are stored already: these go out one by one
+        uint32_t i = 0;
+        for (uint64_t r = gw; r < b.n; r += nw, i++) {
             const KidReadDesc d = descs[r];
             const int64_t nk = (int64_t)__builtin_amdgcn_readfirstlane(d.n_kmers);
             if (nk <= KID_SEG_KMERS) continue;
             uint32_t c0, i0;
             fetch_words(d, c0, i0);
-            process_read(r, uniform64(d.first_base), nk, c0, i0, []() {});
+            process_read(r, i, uniform64(d.first_base), nk, c0, i0, []() {});
+            if (MINLOC && (qn || cur_tag != 0xFFFFFFFFu)) resolve_all(i, 0xFFFFFFFFu);
         }
     }
+    if (MINLOC && lane == 0) atomicAdd(WL, (unsigned long long)n_lookups);
     if (!HIST && pend_n && lane == 0) atomicAdd(&rare->gcount[pend_t], (unsigned long long)pend_n);
 
-    // ---- flush (the pair kernel's histogram packs two 16-bit counters per word: the host keeps a
-    // workgroup below 65536 reads per launch)
+    // ---- flush (with the minimizer-localised table the histogram packs two 16-bit counters per word:
+    // the host keeps a workgroup below 65536 reads per launch)
     if (HIST) {
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < hist_words; i += blockDim.x) {
             const uint32_t v = hist[i];
-            if (PAIRK) {
+            if (MINLOC) {
                 if (v & 0xFFFFu) atomicAdd(&rare->gcount[2u * i], (unsigned long long)(v & 0xFFFFu));
                 if (v >> 16) atomicAdd(&rare->gcount[2u * i + 1u], (unsigned long long)(v >> 16));
             } else if (v) atomicAdd(&rare->gcount[i], (unsigned long long)v);
