@@ -144,12 +144,16 @@ int kid_sample_end(kid_sample *s, int64_t *gcount, int64_t *ucount);
 /* {reads, k-mer lookups, table cells read, k-mer hits} so far (synchronises) */
 int kid_sample_stats(kid_sample *s, uint64_t out[4]);
 
-/* Kernel timing for benchmarks: when enabled, every batch records HIP event pairs around its
- * kid_classify_kernel launches (on the launch stream; each launch between its own pair, so gaps
- * between launches do not count).  kid_sample_kernel_time synchronises, adds up the elapsed times
- * since the last call and returns the number of batches they belong to.                        */
+/* Kernel timing for benchmarks: when enabled, every batch records a HIP event pair around its
+ * kid_classify_kernel launches (on the launch stream).  kid_sample_kernel_time synchronises, adds
+ * up the elapsed times since the last call and returns the number of batches they belong to.  */
 int kid_sample_set_timing(kid_sample *s, int enabled);
 int kid_sample_kernel_time(kid_sample *s, double *total_ms, uint64_t *launches);
+/* The same interval on the device's own clock, always on: the first workgroup of kid_classify_kernel to
+ * start and the last one to finish stamp the 100 MHz realtime counter.  Sum over the batches since
+ * the last call (or kid_sample_reset) and their number.  No event overhead, comparable with a
+ * rocprofv3 kernel trace.                                                                      */
+int kid_sample_kernel_time_device(kid_sample *s, double *total_ms, uint64_t *launches);
 
 /* ---- multi-GPU merge helpers (reads sharded over ranks, DB replicated) ---------
  * ucount is |distinct DB k-mers hit| and is not additive over shards: ranks

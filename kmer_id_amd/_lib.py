@@ -52,6 +52,7 @@ PROTOTYPES = {
     "kid_sample_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kid_sample_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "kid_sample_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), c_u64p]),
+    "kid_sample_kernel_time_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), c_u64p]),
     "kid_sample_seen_bytes": (C.c_int, [C.c_void_p, c_u64p]),
     "kid_sample_seen_export": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]),
     "kid_sample_seen_or": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]),

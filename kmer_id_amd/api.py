@@ -172,6 +172,12 @@ class Sample:
         check(self._lib.kid_sample_kernel_time(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def kernel_time_device(self):
+        """-> (total ms, batches) of kid_classify_kernel since the last call, on the device's own 100 MHz clock"""
+        ms, n = C.c_double(0), C.c_uint64(0)
+        check(self._lib.kid_sample_kernel_time_device(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def seen_bytes(self):
         n = C.c_uint64(0)
         check(self._lib.kid_sample_seen_bytes(self._h, C.byref(n)))

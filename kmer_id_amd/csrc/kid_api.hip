@@ -501,7 +501,9 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
 // two instantiations of kid_classify_kernel (512-thread workgroups = 8 waves, persistent over the
 // reads; pair loop / general loops -- the one the batch is not for returns at once; the gcount
 // histogram lives in LDS when 4 workgroups per CU still fit).
-static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_nbytes, hipStream_t stream)
+// max_kmers: the largest n_kmers of the batch when the host knows it (then only the kernel the batch is for is
+// launched), -1 when only the device does
+static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_nbytes, hipStream_t stream, int64_t max_kmers)
 {
     kid_db *db = s->db;
     if (b.n == 0) return KID_OK;
@@ -565,22 +567,16 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
         if (db->info.k == 30) KID_LAUNCH1(R, H, true, 30, true);                                                               \
         else KID_LAUNCH1(R, H, true, 0, true);                                                                                 \
     } while (0)
-    if (ml && KID_PAIRS) {
+    const bool want_pair = ml && KID_PAIRS && (max_kmers < 0 || max_kmers <= 2 * 64);
+    const bool want_general = !(ml && KID_PAIRS) || max_kmers < 0 || max_kmers > 2 * 64;
+    if (want_pair) {
         if (rows && hist_pair) KID_LAUNCH_PK(true, true);
         else if (rows) KID_LAUNCH_PK(true, false);
         else if (hist_pair) KID_LAUNCH_PK(false, true);
         else KID_LAUNCH_PK(false, false);
-        if (s->timing) { // each of the two kernels between its own pair of events: the gap between them is not kernel time
-            hipEvent_t evm0 = nullptr, evm1 = nullptr;
-            KID_HIP(hipEventCreate(&evm0));
-            KID_HIP(hipEventCreate(&evm1));
-            KID_HIP(hipEventRecord(evm0, stream));
-            s->timed.emplace_back(ev0, evm0);
-            KID_HIP(hipEventRecord(evm1, stream));
-            ev0 = evm1;
-        }
     }
-    if (rows && hist && ml) KID_LAUNCH(true, true, true);
+    if (!want_general) { }
+    else if (rows && hist && ml) KID_LAUNCH(true, true, true);
     else if (rows && hist) KID_LAUNCH(true, true, false);
     else if (rows && ml) KID_LAUNCH(true, false, true);
     else if (rows) KID_LAUNCH(true, false, false);
@@ -628,6 +624,24 @@ extern "C" int kid_sample_kernel_time(kid_sample *s, double *total_ms, uint64_t 
     return KID_OK;
 }
 
+extern "C" int kid_sample_kernel_time_device(kid_sample *s, double *total_ms, uint64_t *launches)
+{
+    if (!s || !total_ms || !launches) return kid_fail(KID_ERR_ARG, "null argument");
+    int rc = kid_use_device(s->db->device);
+    if (rc != KID_OK) return rc;
+    KID_HIP(hipDeviceSynchronize());
+    unsigned long long st[32];
+    KID_HIP(hipMemcpy(st, s->stats, sizeof(st), hipMemcpyDeviceToHost));
+    unsigned long long ticks = st[6], n = st[7];
+    if (st[31] > st[30]) { ticks += st[31] - st[30]; n++; } // the batch after which no other was prepared
+    const unsigned long long zero4[2] = {0, 0};
+    KID_HIP(hipMemcpy(s->stats + 6, zero4, 16, hipMemcpyHostToDevice));
+    KID_HIP(hipMemcpy(s->stats + 30, zero4, 16, hipMemcpyHostToDevice));
+    *total_ms = (double)ticks / 1e5; // s_memrealtime: 100 MHz
+    *launches = n;
+    return KID_OK;
+}
+
 extern "C" int kid_classify_batch_device(kid_sample *s, const void *d_bases, uint64_t bases_nbytes, const void *d_offsets,
                                          const void *d_start, const void *d_stop, uint64_t n_reads, void *d_out_final_targ,
                                          void *stream)
@@ -645,7 +659,7 @@ extern "C" int kid_classify_batch_device(kid_sample *s, const void *d_bases, uin
     b.out_final = (uint32_t *)d_out_final_targ;
     b.n = n_reads;
     b.fixed_len = 0;
-    return kid_launch_classify(s, b, bases_nbytes, (hipStream_t)stream);
+    return kid_launch_classify(s, b, bases_nbytes, (hipStream_t)stream, -1);
 }
 
 extern "C" int kid_classify_fixed_device(kid_sample *s, const void *d_bases, uint32_t read_len, uint64_t n_reads,
@@ -661,7 +675,8 @@ extern "C" int kid_classify_fixed_device(kid_sample *s, const void *d_bases, uin
     b.out_final = (uint32_t *)d_out_final_targ;
     b.n = n_reads;
     b.fixed_len = read_len;
-    return kid_launch_classify(s, b, n_reads * (uint64_t)read_len, (hipStream_t)stream);
+    const int64_t nk = (int64_t)read_len - s->db->info.k + 1;
+    return kid_launch_classify(s, b, n_reads * (uint64_t)read_len, (hipStream_t)stream, nk > 0 ? nk : 0);
 }
 
 extern "C" int kid_classify_batch(kid_sample *s, const uint8_t *bases, const uint64_t *offsets, const int32_t *start,
@@ -671,9 +686,12 @@ extern "C" int kid_classify_batch(kid_sample *s, const uint8_t *bases, const uin
     if (n_reads == 0) return KID_OK;
     if (!bases || !offsets) return kid_fail(KID_ERR_ARG, "null argument");
     if ((start == nullptr) != (stop == nullptr)) return kid_fail(KID_ERR_ARG, "start and stop must both be given or both be null");
+    int64_t max_kmers = 0;
     for (uint64_t r = 0; r < n_reads; r++) {
         if (offsets[r + 1] < offsets[r]) return kid_fail(KID_ERR_ARG, "offsets not monotone at read %llu", (unsigned long long)r);
         const uint64_t len = offsets[r + 1] - offsets[r];
+        const int64_t span = start ? (int64_t)stop[r] - (int64_t)start[r] + 1 : (int64_t)len;
+        if (span - s->db->info.k + 1 > max_kmers) max_kmers = span - s->db->info.k + 1;
         if (len > 0x7FFFFFFFull) return kid_fail(KID_ERR_ARG, "read %llu longer than 2^31-1", (unsigned long long)r);
         if (start && start[r] <= stop[r] && (start[r] < 0 || (uint64_t)stop[r] >= len))
             return kid_fail(KID_ERR_ARG, "read %llu: [start,stop] = [%d,%d] outside the read of length %llu (string::at would throw)",
@@ -723,7 +741,7 @@ extern "C" int kid_classify_batch(kid_sample *s, const uint8_t *bases, const uin
     b.stop = start ? s->st_stop : nullptr;
     b.out_final = s->st_out;
     b.n = n_reads;
-    rc = kid_launch_classify(s, b, nbytes, st);
+    rc = kid_launch_classify(s, b, nbytes, st, max_kmers);
     if (rc != KID_OK) return rc;
     if (out_final_targ) KID_HIP(hipMemcpyAsync(out_final_targ, s->st_out, n_reads * 4, hipMemcpyDeviceToHost, st));
     KID_HIP(hipStreamSynchronize(st));

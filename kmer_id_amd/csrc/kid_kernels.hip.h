@@ -286,6 +286,14 @@ __device__ __forceinline__ void kid_pack16(const uint4 v, const uint32_t u_is_t,
 // [start, stop] -> descriptor; the range checks the reference leaves to string::at() happen here
 __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, unsigned long long *stats, KidRareArgs *rare, uint32_t seq)
 {
+    // device-clock bracket of the classify kernel (kid_sample_kernel_time_device): bank the interval of the
+    // batch before, arm the slots for this one.  stats[30] = first start, stats[31] = last end (100 MHz ticks)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long a = stats[30], z = stats[31];
+        if (z > a) { stats[6] += z - a; stats[7] += 1; }
+        stats[30] = ~0ull;
+        stats[31] = 0;
+    }
     uint32_t bad = 0, mx = 0;
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < b.n; r += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t off;
@@ -382,6 +390,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         const bool pairs = (uint32_t)rare->batch_max <= (uint32_t)(U * 64);
         if (pairs != PAIRK) return;
     }
+    if (threadIdx.x == 0) atomicMin(&s.stats[30], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     // (descs == b.desc, passed once more as a restrict-qualified argument: the wave-uniform
     //  descriptor loads then become scalar loads, which stay in flight until first use)
     extern __shared__ uint32_t kid_smem[];
@@ -1210,6 +1219,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
 #ifdef KID_ABLATE
     if (sink == 0x12345678u) atomicAdd(&rare->stats[7], 1ull);
 #endif
+    if (threadIdx.x == 0) atomicMax(&s.stats[31], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     if (lane == 0) {
         const unsigned long long tl = *WL, n_reads = gw < b.n ? (b.n - gw + nw - 1) / nw : 0ull; // reads r = gw + i nw
         const uint32_t n_hits = WC[2];
