@@ -718,7 +718,10 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         if (b.out_final && lane < n && !((rb_skip >> ((i0 + lane) & 63u)) & 1ull))
             kid_store_u32_nowait(&b.out_final[gw32 + (i0 + lane) * nw32], RB[(i0 + lane) & 63u]);
         rb_skip = 0;
+        RB[lane] = 0; // (a read without any hit does not write its slot: see commit_zero)
     };
+    if (MINLOC) RB[lane] = 0;
+    uint32_t n_zero = 0;    // wave-uniform: reads classified as 0 that have not been added to gcount[0] yet
     uint32_t qn = 0;        // wave-uniform fill of the queue
     uint32_t n_lookups = 0; // wave-uniform; per wave and launch: stays below 2^32 for batches of < 2^31 reads x 128 k-mers (longer reads: mod 2^32 is accepted for this counter)
     // the read the resolver left open (its run ended a chunk, or it is still being classified), and its fold so far
@@ -735,6 +738,12 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         }
         if (rb_direct) { if (lane == 0 && b.out_final) kid_store_u32_nowait(&b.out_final[gw32 + i * nw32], final_t); }
         else if (lane == 0) RB[i & 63u] = final_t;
+    };
+    // the common case, a read without a single candidate: counted in a scalar register, its result slot is
+    // zero already
+    auto commit_zero = [&](const uint32_t i) {
+        n_zero++;
+        if (rb_direct && lane == 0 && b.out_final) kid_store_u32_nowait(&b.out_final[gw32 + i * nw32], 0u);
     };
     // i_now: number of the newest queued read (all are within 63 of it); open_tag: a read that may still get
     // entries (general loops, between the groups of a read) -- its run is folded but not committed
@@ -970,7 +979,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         }
         if constexpr (MINLOC) {
             n_lookups += (nk > 0 ? (uint32_t)nk : 0u) - n_bad;
-            if (!had) commit(i, 0u); // (else the resolver commits it, now that it is closed)
+            if (!had) commit_zero(i); // (else the resolver commits it, now that it is closed)
         } else {
             finish_read(r, final_t, (nk > 0 ? (uint32_t)nk : 0u) - n_bad);
         }
@@ -1041,7 +1050,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         }
         if constexpr (MINLOC) {
             n_lookups += (nk > 0 ? (uint32_t)nk : 0u) - n_bad;
-            if (!had) commit(i, 0u); // (else the resolver commits it, now that it is closed)
+            if (!had) commit_zero(i); // (else the resolver commits it, now that it is closed)
         } else {
             finish_read(r, final_t, (nk > 0 ? (uint32_t)nk : 0u) - n_bad);
         }
@@ -1130,7 +1139,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             gA.hd[0] = make_uint4(hA0.x, hA0.y, hA0.z, hA0.w);
             gA.hd[1] = make_uint4(hA1.x, hA1.y, hA1.z, hA1.w);
             n_lookups += nkA - badA;
-            if (!back_deferred(gA, i)) commit(i, 0u);
+            if (!back_deferred(gA, i)) commit_zero(i);
             else if (qn >= KID_CQ_FLUSH) resolve_all(i, 0xFFFFFFFFu);
             KID_TICK(5);
 
@@ -1140,7 +1149,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             gB.hd[1] = make_uint4(hB1.x, hB1.y, hB1.z, hB1.w);
             if (i + 1u < cnt) { // (a wave with an odd number of reads: B is a phantom of zero k-mers)
                 n_lookups += nkB - badB;
-                if (!back_deferred(gB, i + 1u)) commit(i + 1u, 0u);
+                if (!back_deferred(gB, i + 1u)) commit_zero(i + 1u);
                 else if (qn >= KID_CQ_FLUSH) resolve_all(i + 1u, 0xFFFFFFFFu);
             }
             KID_TICK(7);
@@ -1198,6 +1207,10 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         }
     }
     if (MINLOC && lane == 0) atomicAdd(WL, (unsigned long long)n_lookups);
+    if (MINLOC && n_zero && lane == 0) {
+        if (HIST) atomicAdd(&hist[0], n_zero); // low half = target 0; a workgroup stays below 65536 reads
+        else atomicAdd(&rare->gcount[0], (unsigned long long)n_zero);
+    }
     if (!HIST && pend_n && lane == 0) atomicAdd(&rare->gcount[pend_t], (unsigned long long)pend_n);
 
     // ---- flush (with the minimizer-localised table the histogram packs two 16-bit counters per word:
