@@ -558,22 +558,30 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
                        db->d, pk, sd, (H) ? ((PK) ? hist_words16 : hist_words) : 0u, pk.desc, s->d_rare)
 #define KID_LAUNCH(R, H, M)                                                                                                    \
     do {                                                                                                                       \
-        if (db->info.k == 30) KID_LAUNCH1(R, H, M, 30, false);                                                                 \
-        else KID_LAUNCH1(R, H, M, 0, false);                                                                                   \
+        if (db->info.k == 30) KID_LAUNCH1(R, H, M, 30, 0);                                                                     \
+        else KID_LAUNCH1(R, H, M, 0, 0);                                                                                       \
     } while (0)
     // the minimizer-localised table has two kernels per batch (see kid_classify_kernel): pair loop, general loops
-#define KID_LAUNCH_PK(R, H)                                                                                                    \
+#define KID_LAUNCH_PK(R, H, MODE)                                                                                              \
     do {                                                                                                                       \
-        if (db->info.k == 30) KID_LAUNCH1(R, H, true, 30, true);                                                               \
-        else KID_LAUNCH1(R, H, true, 0, true);                                                                                 \
+        if (db->info.k == 30) KID_LAUNCH1(R, H, true, 30, MODE);                                                               \
+        else KID_LAUNCH1(R, H, true, 0, MODE);                                                                                 \
     } while (0)
+    // kernel 1: pairs of single-group reads (<= 128 k-mers); kernel 2: the two groups of a read (<= 256); kernel 0: the rest
     const bool want_pair = ml && KID_PAIRS && (max_kmers < 0 || max_kmers <= 2 * 64);
-    const bool want_general = !(ml && KID_PAIRS) || max_kmers < 0 || max_kmers > 2 * 64;
+    const bool want_duo = ml && KID_PAIRS && (max_kmers < 0 || (max_kmers > 2 * 64 && max_kmers <= 4 * 64));
+    const bool want_general = !(ml && KID_PAIRS) || max_kmers < 0 || max_kmers > 4 * 64;
     if (want_pair) {
-        if (rows && hist_pair) KID_LAUNCH_PK(true, true);
-        else if (rows) KID_LAUNCH_PK(true, false);
-        else if (hist_pair) KID_LAUNCH_PK(false, true);
-        else KID_LAUNCH_PK(false, false);
+        if (rows && hist_pair) KID_LAUNCH_PK(true, true, 1);
+        else if (rows) KID_LAUNCH_PK(true, false, 1);
+        else if (hist_pair) KID_LAUNCH_PK(false, true, 1);
+        else KID_LAUNCH_PK(false, false, 1);
+    }
+    if (want_duo) {
+        if (rows && hist_pair) KID_LAUNCH_PK(true, true, 2);
+        else if (rows) KID_LAUNCH_PK(true, false, 2);
+        else if (hist_pair) KID_LAUNCH_PK(false, true, 2);
+        else KID_LAUNCH_PK(false, false, 2);
     }
     if (!want_general) { }
     else if (rows && hist && ml) KID_LAUNCH(true, true, true);

@@ -379,7 +379,7 @@ struct KidGroup {      // a group of U*64 windows between its two halves
 // every batch and the one the batch is not for returns at once (kid_prepare_kernel left the longest
 // read of the batch in rare->batch_max).  Separate kernels, because each loop wants all 64 vector
 // registers of an 8-waves-per-SIMD kernel for itself.
-template <int U, bool ROWS, bool HIST, bool MINLOC, int KFIX, bool PAIRK>
+template <int U, bool ROWS, bool HIST, bool MINLOC, int KFIX, int PAIRK>
 __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(const KidDevDb db, const KidPacked b, const KidSampleDev s,
                                                             const uint32_t hist_words,
                                                             const KidReadDesc *__restrict__ const descs,
@@ -387,8 +387,9 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
 {
     static_assert(!PAIRK || (MINLOC && U == 2), "the pair loop exists for the minimizer-localised table, two windows per lane");
     if (MINLOC && KID_PAIRS) { // wave-uniform, before anything else
-        const bool pairs = (uint32_t)rare->batch_max <= (uint32_t)(U * 64);
-        if (pairs != PAIRK) return;
+        const uint32_t longest = (uint32_t)rare->batch_max;
+        const int mode = longest <= (uint32_t)(U * 64) ? 1 : longest <= (uint32_t)(2 * U * 64) ? 2 : 0;
+        if (mode != PAIRK) return;
     }
     if (threadIdx.x == 0) atomicMin(&s.stats[30], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     // (descs == b.desc, passed once more as a restrict-qualified argument: the wave-uniform
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         const unsigned long long rt0 = __builtin_amdgcn_s_memtime();
 #endif
         // (the pair kernel never leaves a read open between calls: its carry lives and dies in here)
-        uint32_t ctag = PAIRK ? 0xFFFFFFFFu : cur_tag, final_t = PAIRK ? 0u : final_c, vfrow = PAIRK ? 0u : vfrow_c;
+        uint32_t ctag = PAIRK == 1 ? 0xFFFFFFFFu : cur_tag, final_t = PAIRK == 1 ? 0u : final_c, vfrow = PAIRK == 1 ? 0u : vfrow_c;
         auto commit_tag = [&](const uint32_t tag, const uint32_t f) {
             commit(i_now - ((i_now - tag) & 63u), f);
         };
@@ -907,7 +908,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             }
         }
         if (ctag != 0xFFFFFFFFu && ctag != open_tag) { commit_tag(ctag, final_t); ctag = 0xFFFFFFFFu; }
-        if (!PAIRK) { cur_tag = ctag; final_c = final_t; vfrow_c = vfrow; }
+        if (PAIRK != 1) { cur_tag = ctag; final_c = final_t; vfrow_c = vfrow; }
         qn = 0;
 #ifdef KID_PROFILE
         prof[9] += __builtin_amdgcn_s_memtime() - rt0; // (also contained in the phase that called)
@@ -1067,7 +1068,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
     // assembly, unconditionally (idle lanes read cell 0), and waited for with explicit counts.  Loads
     // return in order, and anything the compiler issues in between (hit cells, atomics, the out_final
     // store) only makes an explicit count stricter than needed.
-    if constexpr (PAIRK) {
+    if constexpr (PAIRK != 0) {
         const uint32_t cnt = gw < b.n ? (uint32_t)((b.n - gw + nw - 1) / nw) : 0u; // reads of this wave: gw + i nw
         const uint32_t lane4 = lane * 4u;
         // descriptors, 64 at a time: lane l holds the one of read number blk + l of this wave -- the low word
@@ -1105,6 +1106,51 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         uint32_t cA, iA, cB, iB;
         issue_words(0u, cA, iA);
         issue_words(1u, cB, iB);
+        if constexpr (PAIRK == 2) {
+            // ---- reads of two groups (129..256 k-mers: 2 x 250 bp): the pair is the two groups of ONE read.
+            // They share the read's packed words, their queue entries carry the same tag, and the read
+            // stays open in the resolver between them.  Two word sets alternate, each requested two trips
+            // ahead (a trip is one read here).
+            auto duo = [&](const uint32_t i, uint32_t &cC, uint32_t &iC) { // (cC, iC): the word set that holds read i
+                const uint32_t ia = i - blk;
+                const uint32_t nk = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)ia) >> 16;
+                const uint32_t sh = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)ia) & 15u;
+                const uint32_t nb = nk + (uint32_t)k - 1;
+                KidGroup<U> gA, gB;
+                uint32_t bad = 0;
+                if (ia + 2u > 63u) { blk = i + 1u; load_block(); } // (this read's descriptor is in scalars by now)
+                asm volatile("s_waitcnt vmcnt(2)" : "+v"(cC), "+v"(iC) : : "memory"); // behind: the words of the next read (other set)
+                const bool cl = (__ballot(iC != 0) == 0);
+                group_front(nullptr, sh, nb, nk, 0u, cl, gA, bad, false, cC, iC);
+                kid_u4 hA0 = issue_header(gA, 0), hA1 = issue_header(gA, 1);
+                group_front(nullptr, sh, nb, nk, (uint32_t)(U * 64), cl, gB, bad, false, cC, iC);
+                kid_u4 hB0 = issue_header(gB, 0), hB1 = issue_header(gB, 1);
+                issue_words(i + 2u - blk, cC, iC); // this set is used up: the read after the next, two trips ahead
+                n_lookups += nk - bad;
+                asm volatile("s_waitcnt vmcnt(4)" : "+v"(hA0), "+v"(hA1) : : "memory"); // behind: the headers of B, the words just requested
+                gA.hd[0] = make_uint4(hA0.x, hA0.y, hA0.z, hA0.w);
+                gA.hd[1] = make_uint4(hA1.x, hA1.y, hA1.z, hA1.w);
+                bool had = back_deferred(gA, i);
+                if (qn >= KID_CQ_FLUSH) resolve_all(i, i & 63u); // the read stays open
+                asm volatile("s_waitcnt vmcnt(2)" : "+v"(hB0), "+v"(hB1) : : "memory"); // behind: the words just requested
+                gB.hd[0] = make_uint4(hB0.x, hB0.y, hB0.z, hB0.w);
+                gB.hd[1] = make_uint4(hB1.x, hB1.y, hB1.z, hB1.w);
+                had |= back_deferred(gB, i);
+                if (!had) commit_zero(i);
+                else if (qn >= KID_CQ_FLUSH) resolve_all(i, 0xFFFFFFFFu);
+                if (((i + 1u) & 63u) == 0u) { // tags and result slots are read numbers mod 64
+                    if (qn || cur_tag != 0xFFFFFFFFu) resolve_all(i, 0xFFFFFFFFu);
+                    flush_results(i + 1u - 64u, 64u);
+                }
+            };
+            for (uint32_t i = 0; i < cnt; i += 2) {
+                duo(i, cA, iA);
+                if (i + 1u < cnt) duo(i + 1u, cB, iB);
+            }
+            if (qn || cur_tag != 0xFFFFFFFFu) resolve_all(cnt - 1u, 0xFFFFFFFFu);
+            if (cnt & 63u) flush_results(cnt & ~63u, cnt & 63u);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cA), "+v"(iA), "+v"(cB), "+v"(iB) : : "memory");
+        } else {
         for (uint32_t i = 0; i < cnt; i += 2) {
             const uint32_t ia = i - blk;
             const uint32_t nkA = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)ia) >> 16;
@@ -1161,9 +1207,10 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         if (qn) resolve_all(cnt - 1u, 0xFFFFFFFFu);
         if (cnt & 63u) flush_results(cnt & ~63u, cnt & 63u);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(cA), "+v"(iA), "+v"(cB), "+v"(iB) : : "memory");
+        }
     }
 #endif
-    if constexpr (!PAIRK) {
+    if constexpr (PAIRK == 0) {
         // Software pipeline, unrolled by two with two named register sets (A, B) so that nothing is
         // copied between stages: the descriptor of a read is requested two reads ahead (scalar loads)
         // and its first packed words one read ahead; the waits the compiler places in front of their
@@ -1193,7 +1240,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         }
     }
     // ---- phase 2: the long reads this wave met (FASTA records, long-read data), one at a time
-    if (!PAIRK && any_long) {
+    if (PAIRK == 0 && any_long) {
         rb_direct = true; // the other reads' results are stored already: these go out one by one
         uint32_t i = 0;
         for (uint64_t r = gw; r < b.n; r += nw, i++) {

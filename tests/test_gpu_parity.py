@@ -610,11 +610,13 @@ def _genome_db(parent, n_genomes, genome_len, rng):
     return genomes, np.concatenate(keys), np.concatenate(targets)
 
 
-@pytest.mark.parametrize("read_len", [150, 157, 100])
+@pytest.mark.parametrize("read_len", [150, 157, 100, 250, 285, 286])
 def test_dense_hits_through_the_lookup_queue(read_len):
     """Reads cut from genomes whose every k-mer is in the DB: up to 128 queued lookups per read, runs
     of one read split over resolver chunks, more than 64 reads per wave (tags wrap), both strands,
-    mutated copies with fewer hits, masked bases and reads without any hit in between."""
+    mutated copies with fewer hits, masked bases and reads without any hit in between.  157 bp = 128
+    k-mers (the largest single group), 250 / 285 bp = two groups per read (a read stays open in the
+    resolver between them), 286 bp = 257 k-mers (general loops)."""
     parent, _ = synth.load_taxonomy("bact10")
     rng = np.random.default_rng(77 + read_len)
     genomes, keys, targets = _genome_db(parent, 120, 2500, rng)
