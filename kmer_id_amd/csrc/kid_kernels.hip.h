@@ -910,6 +910,9 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         if (ctag != 0xFFFFFFFFu && ctag != open_tag) { commit_tag(ctag, final_t); ctag = 0xFFFFFFFFu; }
         if (PAIRK != 1) { cur_tag = ctag; final_c = final_t; vfrow_c = vfrow; }
         qn = 0;
+        // a real s_waitcnt (not inline assembly): hipcc's waitcnt pass then knows that none of ITS loads is
+        // pending when this rare path rejoins the loop, and does not drain vmcnt at the top of every trip
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), expcnt and lgkmcnt untouched
 #ifdef KID_PROFILE
         prof[9] += __builtin_amdgcn_s_memtime() - rt0; // (also contained in the phase that called)
 #endif
