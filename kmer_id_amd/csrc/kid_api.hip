@@ -60,6 +60,7 @@ struct kid_sample {
     // per-batch scratch of the device pipeline (prepare -> pack -> classify), grown on demand
     KidRareArgs *d_rare = nullptr; // device copy, written once in kid_sample_begin (batch_max: by every batch)
     uint32_t batch_seq = 0;
+    uint64_t reads_submitted = 0; // since the last reset: checked against the device's count when results are read
     KidReadDesc *sc_desc = nullptr;
     uint64_t sc_desc_cap = 0;
     uint32_t *sc_codes = nullptr;
@@ -456,6 +457,7 @@ extern "C" int kid_sample_reset(kid_sample *s)
     KID_HIP(hipMemset(s->gcount, 0, nt * 8));
     KID_HIP(hipMemset(s->ucount, 0, nt * 8));
     KID_HIP(hipMemset(s->stats, 0, 256));
+    s->reads_submitted = 0;
     KID_HIP(hipMemset(s->seen, 0, s->seen_words * 4));
     KID_HIP(hipDeviceSynchronize());
     return KID_OK;
@@ -601,6 +603,7 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
         s->timed_batches++;
     }
     KID_HIP(hipGetLastError());
+    s->reads_submitted += b.n;
     return KID_OK;
 }
 
@@ -797,6 +800,10 @@ static int kid_check_errors(kid_sample *s)
     KID_HIP(hipMemcpy(st, s->stats, 64, hipMemcpyDeviceToHost));
     if (st[4] != 0)
         return kid_fail(KID_ERR_ARG, "%llu reads had [start,stop] outside the read (string::at would throw)", st[4]);
+    // every read handed over was classified by exactly one of the kernels (they pick themselves by the batch's
+    // longest read: a disagreement with the host's choice would show here, not as silently missing reads)
+    if (st[0] != s->reads_submitted)
+        return kid_fail(KID_ERR_STATE, "%llu reads classified, %llu submitted", st[0], (unsigned long long)s->reads_submitted);
     return KID_OK;
 }
 
