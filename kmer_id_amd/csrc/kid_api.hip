@@ -487,7 +487,7 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
     KID_S_HIP(hipMalloc(&s->seen, s->seen_words * 4));
     KID_S_HIP(hipStreamCreate(&s->stream));
     {
-        const KidRareArgs ra{s->gcount, s->stats, db->d.line_mask, 0u, 0ull};
+        const KidRareArgs ra{s->gcount, s->stats, db->d.line_mask, 0u, 0ull, db->rows, s->seen, nullptr, nullptr};
         KID_S_HIP(hipMalloc(&s->d_rare, sizeof(ra)));
         KID_S_HIP(hipMemcpy(s->d_rare, &ra, sizeof(ra), hipMemcpyHostToDevice));
     }

@@ -125,6 +125,12 @@ struct KidRareArgs {
     uint32_t line_mask;
     uint32_t pad;
     unsigned long long batch_max; // (batch sequence number << 32) | largest n_kmers of the batch: kid_prepare_kernel
+    // what the resolver / the 64-read flush of the pair kernels need (rare paths by now, bulk work: a scalar
+    // load there is cheaper than four scalar registers held across the hot loop)
+    const uint4 *rows;
+    uint32_t *seen;
+    uint32_t *out_final;   // of the current batch: written by kid_prepare_kernel
+    const void *desc;      // of the current batch (KidReadDesc *)
 };
 
 // ------------------------------------------------------------------ hash lookup
@@ -293,6 +299,8 @@ __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, u
         if (z > a) { stats[6] += z - a; stats[7] += 1; }
         stats[30] = ~0ull;
         stats[31] = 0;
+        rare->out_final = b.out_final;
+        rare->desc = desc;
     }
     uint32_t bad = 0, mx = 0;
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < b.n; r += (uint64_t)gridDim.x * blockDim.x) {
@@ -716,8 +724,9 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
     uint64_t rb_skip = 0;   // result slots of the current block of 64 reads that are not this pass's to store
     bool rb_direct = false; // second pass of the general loops (reads of more than one segment): results stored at once
     auto flush_results = [&](const uint32_t i0, const uint32_t n) { // this wave's reads i0 .. i0+n-1 (n <= 64)
-        if (b.out_final && lane < n && !((rb_skip >> ((i0 + lane) & 63u)) & 1ull))
-            kid_store_u32_nowait(&b.out_final[gw32 + (i0 + lane) * nw32], RB[(i0 + lane) & 63u]);
+        uint32_t *const outp = rare->out_final;
+        if (outp && lane < n && !((rb_skip >> ((i0 + lane) & 63u)) & 1ull))
+            kid_store_u32_nowait(&outp[gw32 + (i0 + lane) * nw32], RB[(i0 + lane) & 63u]);
         rb_skip = 0;
         RB[lane] = 0; // (a read without any hit does not write its slot: see commit_zero)
     };
@@ -801,8 +810,8 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             }
             uint4 row = make_uint4(0, 0, 0, 0);
             if (tgt > 0) {
-                if (ROWS) row = db.rows[tgt];
-                if (tgt > 1) kid_atomic_or_nowait(&s.seen[slot >> 5], 1u << (slot & 31u));
+                if (ROWS) row = rare->rows[tgt];
+                if (tgt > 1) kid_atomic_or_nowait(&rare->seen[slot >> 5], 1u << (slot & 31u));
             }
             const uint64_t hitm = __ballot(tgt > 0);
             if (hitm && lane == 0) atomicAdd(&WC[2], (uint32_t)__popcll(hitm));
@@ -1082,7 +1091,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             const uint64_t rr = gw + (uint64_t)(blk + lane) * nw;
             dv_lo = 0; dv_hn = 0;
             if (rr < b.n) {
-                const KidReadDesc d = b.desc[rr];
+                const KidReadDesc d = static_cast<const KidReadDesc *>(rare->desc)[rr];
                 dv_lo = (uint32_t)d.first_base;
                 dv_hn = ((uint32_t)(d.first_base >> 32) & 0xFFFFu) | ((d.n_kmers > 0 ? (uint32_t)d.n_kmers : 0u) << 16);
             }
