@@ -39,12 +39,11 @@
 
 typedef uint32_t kid_u4 __attribute__((ext_vector_type(4)));
 
-// One table cell.  Non-temporal: a probe touches a random 16 bytes of a 16 GiB table once, so
-// the line is not worth keeping in L2 / Infinity Cache (measured: tools/gather_policy.hip,
-// 49 -> 54 G random cells/s on a 16 GiB region).
-#ifndef KID_NT
-#define KID_NT 1
-#endif
+// One table cell.  Reference placement: non-temporal -- a probe touches a random 16 bytes of a 16 GiB
+// table once, so the line is not worth keeping in L2 / Infinity Cache (tools/gather_policy.hip: 49 ->
+// 54 G random cells/s on a 16 GiB region).  Minimizer-localised placement: plain loads -- the header
+// of a line is read again by the resolver and the matching entry sits in the same 128 bytes, so the
+// line should stay cached (measured: 1.29 -> 1.23 ms per launch).
 // Fire-and-forget global writes of the classify kernel (per-read result, seen-bitmap bits).  Issued
 // from inline assembly so that the compiler's waitcnt insertion does not know them: on gfx9 a pending
 // store or no-return atomic shares vmcnt with the loads and makes the next wait a full vmcnt(0) drain,
@@ -59,14 +58,11 @@ __device__ __forceinline__ void kid_atomic_or_nowait(uint32_t *p, uint32_t v)
     asm volatile("global_atomic_or %0, %1, off" : : "v"(p), "v"(v) : "memory");
 }
 
-__device__ __forceinline__ uint4 kid_load_cell(const uint4 *table, uint32_t idx)
+__device__ __forceinline__ uint4 kid_load_cell(const uint4 *table, uint32_t idx) { return table[idx]; }
+__device__ __forceinline__ uint4 kid_load_cell_nt(const uint4 *table, uint32_t idx)
 {
-#if KID_NT
     const kid_u4 v = __builtin_nontemporal_load(reinterpret_cast<const kid_u4 *>(table) + idx);
     return make_uint4(v.x, v.y, v.z, v.w);
-#else
-    return table[idx];
-#endif
 }
 
 struct KidDevDb {
@@ -624,7 +620,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                 for (int u = 0; u < U; u++) {
                     idx[u] = (g.hlo[u] + (uint32_t)rp[u]) & db.slot_mask;
                     c[u] = make_uint4(0, 0, 0, 0);
-                    if (g.act[u]) c[u] = kid_load_cell(db.table, idx[u]);
+                    if (g.act[u]) c[u] = kid_load_cell_nt(db.table, idx[u]);
                 }
                 any = false;
 #pragma unroll
@@ -1107,11 +1103,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         auto issue_header = [&](const KidGroup<U> &g, const int u) -> kid_u4 {
             const uint4 *const p = db.table + (g.act[u] ? g.hlo[u] * KID_LINE_CELLS : 0u);
             kid_u4 v;
-#if KID_NT
-            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(v) : "v"(p) : "memory");
-#else
             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
-#endif
             return v;
         };
         load_block();
