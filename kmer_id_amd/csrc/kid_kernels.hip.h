@@ -351,24 +351,19 @@ __global__ void kid_pack_kernel(const uint8_t *bases, uint64_t nchunks, uint32_t
 }
 
 // ------------------------------------------------------------------ classify
-// One wavefront per read.  Per segment of <= 960 k-mers:
-//   1. every lane copies one packed word (16 bases, 2 bits each) and its invalid mask from the
-//      batch's packed image (kid_pack_kernel) into the wave's private LDS strip;
-//   2. lane i extracts the k-mer window starting at base i from LDS with two
-//      shifts (no serial rolling), derives the reverse complement with a bit
-//      reversal and takes min(); with the minimizer-localised geometry the wave
-//      also computes the sliding-window minimum of the hashed m-mers (DPP row scans
-//      + one cross-lane fetch), which selects the table line;
-//   3. the table is probed in HBM -- U windows per lane in flight at once;
-//   4. hits are folded with msca in read-position order (the fold is not
-//      associative: newkmer_10nx.cpp:588-595) on wave-uniform registers;
-//   5. hit cells are marked in the sample's seen-bitmap (ucount, :596-603).
+// One wavefront per read (DESIGN.md section 4 has the long version).  What a read needs:
+//   1. lane i extracts the k-mer window starting at base i from the read's packed words (16 bases
+//      each; general loops: staged in an LDS strip, pair kernels: fetched with ds_bpermute) with
+//      two shifts -- no serial rolling --, derives the reverse complement with a bit reversal and
+//      takes min(); with the minimizer-localised table the wave also computes the sliding-window
+//      minimum of the hashed m-mers (DPP row scans + one cross-lane fetch), which selects the line;
+//   2. the table is probed in HBM -- U windows per lane in flight at once.  Minimizer-localised
+//      table: one header per lookup, which settles ~99 % of them; the others are queued in LDS and
+//      resolved 64 at a time (candidate cell, ancestor row);
+//   3. hits are folded with msca in read-position order (the fold is not associative:
+//      newkmer_10nx.cpp:588-595);
+//   4. hit cells are marked in the sample's seen-bitmap (ucount, :596-603).
 // gcount is accumulated in an LDS histogram per workgroup and flushed once.
-//
-// A wave is latency-bound (every read is a chain of dependent round trips: LDS strip, table header,
-// hit cell, ancestor row), so short reads -- one group of <= U*64 windows, the Illumina case -- are
-// taken two at a time: steps 1-3a (up to the header loads) of read A, the same of read B, then
-// steps 3b-5 of A and of B, which doubles the table loads a wave keeps in flight.
 template <int U>
 struct KidGroup {      // a group of U*64 windows between its two halves
     uint64_t key[U];
@@ -378,11 +373,12 @@ struct KidGroup {      // a group of U*64 windows between its two halves
     bool act[U];
 };
 
-// Two instantiations per configuration share this body: PAIRK = true holds only the hand-pipelined
-// pair loop (batches of single-group reads), PAIRK = false the general loops; both are launched for
-// every batch and the one the batch is not for returns at once (kid_prepare_kernel left the longest
-// read of the batch in rare->batch_max).  Separate kernels, because each loop wants all 64 vector
-// registers of an 8-waves-per-SIMD kernel for itself.
+// Three instantiations per configuration share this body, picked by the longest read of the batch
+// (kid_prepare_kernel leaves it in rare->batch_max): PAIRK = 1 holds the hand-pipelined pair loop for
+// batches of single-group reads (<= U*64 k-mers), PAIRK = 2 the same loop with the two groups of one
+// read as the pair (<= 2*U*64 k-mers), PAIRK = 0 the general loops.  The host launches the one the
+// batch is for when it knows the longest read, else all three: the others return at once.  Separate
+// kernels, because each loop wants all 64 vector registers of an 8-waves-per-SIMD kernel for itself.
 template <int U, bool ROWS, bool HIST, bool MINLOC, int KFIX, int PAIRK>
 __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(const KidDevDb db, const KidPacked b, const KidSampleDev s,
                                                             const uint32_t hist_words,
