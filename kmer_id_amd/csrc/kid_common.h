@@ -90,6 +90,11 @@ KID_HD int kid_min_mlen(int k) { return k - kid_min_window(k) + 1; }
 #define KID_LINE_CELLS 8    // header + 7 entries
 #define KID_LINE_ENTRIES 7
 #define KID_HDR_FULL 8u     // header count value: 7 entries stored and the chain continues in the next line
+// Word 3 of a header: [15:0] fingerprint of entry 6, [19:16] count (0..7, 8 = full and chained), [31:20] a
+// 12-bit filter of the fingerprints of the keys that were pushed past this line.  A lookup follows the chain
+// only if the line is full AND its key's filter bit is set: lines fill up when a run of consecutive genome
+// k-mers shares one minimizer (up to 15 keys on 7 entries), and without the filter every lookup that lands on
+// a full line -- present or not -- would have to walk on.
 
 KID_HD uint32_t kid_rev2_32(uint32_t x)
 {
@@ -142,6 +147,13 @@ KID_HD uint32_t kid_minimizer_of_key(uint64_t keyF, int k)
 KID_HD uint32_t kid_minloc_line(uint32_t g, uint32_t line_shift)
 {
     return (g * 0xC2B2AE3Du) >> line_shift;
+}
+
+KID_HD uint32_t kid_hdr_count(uint32_t w3) { return (w3 >> 16) & 15u; }
+KID_HD uint32_t kid_ovf_bit(uint32_t fp) { return 20u + ((fp * 12u) >> 16); } // fp < 2^16 -> bits 20..31
+KID_HD bool kid_hdr_continues(uint32_t w3, uint32_t fp)
+{
+    return kid_hdr_count(w3) >= KID_HDR_FULL && ((w3 >> kid_ovf_bit(fp)) & 1u) != 0;
 }
 
 // 16-bit fingerprint of a key kept in the line header; never 0 (0 = unused header slot)

@@ -175,7 +175,7 @@ __device__ __forceinline__ uint32_t kid_bucket_lookup(const KidDevDb &db, uint64
             ncell++;
             if (c.z != 0 && c.x == (uint32_t)key && c.y == (uint32_t)(key >> 32)) { slot = base + 1u + j; return c.z; }
         }
-        if ((h.w >> 16) < KID_HDR_FULL) return 0;
+        if (!kid_hdr_continues(h.w, fp)) return 0;
         line = (line + 1u) & db.line_mask;
     }
 }
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 fp[u] = (g.fpp >> (16 * u)) & 0xFFFFu;
-                mm[u] = (g.act[u] && (kid_hdr_any(g.hd[u], fp[u]) || (g.hd[u].w >> 16) >= KID_HDR_FULL)) ? 1u : 0u;
+                mm[u] = (g.act[u] && (kid_hdr_any(g.hd[u], fp[u]) || kid_hdr_continues(g.hd[u].w, fp[u]))) ? 1u : 0u;
                 more |= mm[u] != 0;
             }
             if (__ballot(more) == 0) return; // (wave-uniform) ~99 % of the lanes are settled by their header
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 m[u] = mm[u] ? kid_hdr_cand(g.hd[u], fp[u]) : 0u;
-                full[u] = mm[u] && (g.hd[u].w >> 16) >= KID_HDR_FULL;
+                full[u] = mm[u] && kid_hdr_continues(g.hd[u].w, fp[u]);
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                         const uint4 h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
                         atomicAdd(&WC[3], 1u);
                         mu = kid_hdr_cand(h, fp[u]);
-                        fu = (h.w >> 16) >= KID_HDR_FULL;
+                        fu = kid_hdr_continues(h.w, fp[u]);
                     } else go = false;
                 }
             }
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             if (valid) {
                 const uint4 h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
                 mu = kid_hdr_cand(h, fp);
-                fu = (h.w >> 16) >= KID_HDR_FULL;
+                fu = kid_hdr_continues(h.w, fp);
             }
             { // (cells read: one add for the wave, not one per lane on the same LDS word)
                 const uint64_t cm = __ballot(mu != 0);
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                     const uint4 h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
                     atomicAdd(&WC[3], 1u);
                     mu = kid_hdr_cand(h, fp);
-                    fu = (h.w >> 16) >= KID_HDR_FULL;
+                    fu = kid_hdr_continues(h.w, fp);
                 } else go = false;
             }
             uint4 row = make_uint4(0, 0, 0, 0);
@@ -925,6 +925,8 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
 #pragma unroll
         for (int u = 0; u < U; u++) {
             fp[u] = (g.fpp >> (16 * u)) & 0xFFFFu;
+            // (a full line: word 3 >= 8 << 16 -- filter bits are only ever set on full lines.  Whether THIS key was
+            //  pushed past it is looked at by the resolver: testing the filter bit here costs the hot loop a register)
             mm[u] = g.act[u] && (kid_hdr_any(g.hd[u], fp[u]) || (g.hd[u].w >> 16) >= KID_HDR_FULL);
             more |= mm[u];
         }
@@ -1373,7 +1375,7 @@ __global__ void kid_build_insert_kernel(uint4 *table, uint32_t slot_mask, const 
                 uint32_t old = __hip_atomic_load(hdr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 uint32_t cnt;
                 for (;;) {
-                    cnt = old >> 16;
+                    cnt = kid_hdr_count(old);
                     if (cnt >= KID_HDR_FULL) break;
                     const uint32_t seen = atomicCAS(hdr + 3, old, old + 0x10000u);
                     if (seen == old) break;
@@ -1389,6 +1391,7 @@ __global__ void kid_build_insert_kernel(uint4 *table, uint32_t slot_mask, const 
                     atomicAdd(n_occupied, 1ull);
                     break;
                 }
+                atomicOr(hdr + 3, 1u << kid_ovf_bit(fp)); // pushed past this line: leave a trace for the lookups
                 line = (line + 1u) & line_mask; // cnt == 7 just became 8 (chain marker) or was 8 already
             }
             continue;
@@ -1429,7 +1432,8 @@ __global__ void kid_build_firstwins_kernel(uint4 *table, uint32_t slot_mask, con
             uint32_t line = kid_minloc_line(kid_minimizer_of_key(key, k), line_shift);
             for (;;) {
                 const uint32_t base = line * KID_LINE_CELLS;
-                const uint32_t cnt = reinterpret_cast<const uint32_t *>(table + base)[3] >> 16;
+                const uint32_t w3 = reinterpret_cast<const uint32_t *>(table + base)[3];
+                const uint32_t cnt = kid_hdr_count(w3);
                 const uint32_t ne = cnt < KID_LINE_ENTRIES ? cnt : KID_LINE_ENTRIES;
                 for (uint32_t j = 0; j < ne; j++) {
                     const uint32_t *c = reinterpret_cast<const uint32_t *>(table + base + 1u + j);
@@ -1440,7 +1444,7 @@ __global__ void kid_build_firstwins_kernel(uint4 *table, uint32_t slot_mask, con
                         copies++;
                     }
                 }
-                if (cnt < KID_HDR_FULL) break;
+                if (!kid_hdr_continues(w3, kid_key_fp(key))) break; // (every copy of this key left its trace on the way)
                 line = (line + 1u) & line_mask;
             }
         } else {
