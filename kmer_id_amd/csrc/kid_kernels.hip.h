@@ -1093,8 +1093,13 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         auto issue_words = [&](const uint32_t idx, uint32_t &c, uint32_t &iv) {
             const uint64_t w0 = (((uint64_t)((uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)idx) & 0xFFFFu) << 32) |
                                  (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)idx)) >> 4;
+#ifdef KID_ABLATE_WORDS // timing experiment only: the packed words always come from the same few cache lines
+            const uint32_t *const pc = b.codes + (w0 & 1023u);
+            const uint16_t *const pi = b.inval + (w0 & 1023u);
+#else
             const uint32_t *const pc = b.codes + w0;
             const uint16_t *const pi = b.inval + w0;
+#endif
             asm volatile("global_load_dword %0, %1, %2" : "=v"(c) : "v"(lane4), "s"(pc) : "memory");
             asm volatile("global_load_ushort %0, %1, %2" : "=v"(iv) : "v"(lane4 >> 1), "s"(pi) : "memory");
         };
