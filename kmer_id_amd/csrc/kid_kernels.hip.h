@@ -510,7 +510,10 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             g.fpp = 0;
 #pragma unroll
             for (int u = 0; u < U; u++) g.fpp |= kid_key_fp(g.key[u]) << (16 * u);
-            { // the win-1 m-mers behind the last k-mer of the group
+            // the win-1 m-mers behind the last k-mer of the group -- if any window of the group reaches that
+            // far (wave-uniform: a 100-bp read ends inside the group, m-mers and all)
+            P[U] = 0xFFFFFFFFu;
+            if (segk + win - 1u > t0 + (uint32_t)U * 64u) {
                 uint32_t p = sh + t0 + (uint32_t)U * 64u + lane;
                 p = p < pmax ? p : pmax;
                 const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
