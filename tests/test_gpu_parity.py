@@ -660,3 +660,24 @@ def test_dense_hits_through_the_lookup_queue(read_len):
     assert st["hits"] > 20 * n  # dense
     s.close()
     db.close()
+
+
+def test_kernel_time_on_two_clocks(seeded):
+    """kid_sample_kernel_time (HIP events) and kid_sample_kernel_time_device (the device's realtime counter,
+    first workgroup start to last workgroup end) bracket the same launches."""
+    parent, cum, keys, targets, odb, db = seeded
+    n, read_len = 400_000, 150
+    bases = synth.reads(cum, parent, n, read_len, K)
+    import torch
+    d = torch.from_numpy(bases).cuda()
+    s = db.sample()
+    s.classify_fixed_device(d.data_ptr(), read_len, n)  # warm-up (scratch allocation)
+    s.set_timing(True)
+    s.kernel_time(); s.kernel_time_device()
+    for _ in range(5):
+        s.classify_fixed_device(d.data_ptr(), read_len, n)
+    ev_ms, ev_n = s.kernel_time()
+    dev_ms, dev_n = s.kernel_time_device()
+    assert ev_n == 5 and dev_n == 5
+    assert 0 < dev_ms <= ev_ms * 1.05 and dev_ms >= ev_ms * 0.5
+    s.close()
