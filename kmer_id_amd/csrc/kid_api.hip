@@ -526,11 +526,11 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
         KID_HIP(hipMalloc(&s->sc_inval, (nchunks + 64) * 2));
         s->sc_chunks_cap = nchunks;
     }
-    hipLaunchKernelGGL(kid_prepare_kernel, dim3(kid_grid_for(b.n, 256, db->num_cu * 8)), dim3(256), 0, stream, b, db->info.k,
-                       s->sc_desc, s->stats, s->d_rare, ++s->batch_seq);
     if (nchunks)
         hipLaunchKernelGGL(kid_pack_kernel, dim3(kid_grid_for(nchunks, 256, db->num_cu * 16)), dim3(256), 0, stream, b.bases,
                            nchunks, db->d.u_is_t, s->sc_codes, s->sc_inval);
+    hipLaunchKernelGGL(kid_prepare_kernel, dim3(kid_grid_for(b.n, 256, db->num_cu * 8)), dim3(256), 0, stream, b, db->info.k,
+                       s->sc_desc, s->stats, s->d_rare, ++s->batch_seq, nchunks ? s->sc_inval : nullptr);
     KidPacked pk{s->sc_codes, s->sc_inval, s->sc_desc, b.out_final, b.n};
     const int block = 512, wpb = block / 64;
     const uint32_t ntar = (uint32_t)db->info.ntar;

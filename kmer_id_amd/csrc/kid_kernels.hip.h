@@ -286,7 +286,9 @@ __device__ __forceinline__ void kid_pack16(const uint4 v, const uint32_t u_is_t,
 
 // ------------------------------------------------------------------ batch preparation
 // [start, stop] -> descriptor; the range checks the reference leaves to string::at() happen here
-__global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, unsigned long long *stats, KidRareArgs *rare, uint32_t seq)
+// (runs after kid_pack_kernel: `inval` is the packed invalid-mask image of the batch)
+__global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, unsigned long long *stats, KidRareArgs *rare, uint32_t seq,
+                                   const uint16_t *inval)
 {
     // device-clock bracket of the classify kernel (kid_sample_kernel_time_device): bank the interval of the
     // batch before, arm the slots for this one.  stats[30] = first start, stats[31] = last end (100 MHz ticks)
@@ -316,7 +318,16 @@ __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, u
         if (s0 > e0) nk = 0;
         d.first_base = off + (uint64_t)(s0 > 0 ? s0 : 0);
         d.n_kmers = (int32_t)(nk > 0x7FFFFFFF ? 0x7FFFFFFF : nk);
-        d.pad = 0;
+        // pad bit 0: "some base of the read may reset a window" -- short reads are checked against the packed
+        // mask (their 16-base chunks, a little more than the classified range), so that the classify kernel
+        // need not fetch the mask of a clean read; longer reads are simply called dirty
+        d.pad = d.n_kmers > 0 ? 1u : 0u;
+        if (d.n_kmers > 0 && d.n_kmers <= 256 && inval) {
+            const uint64_t c0 = d.first_base >> 4, c1 = (d.first_base + (uint64_t)d.n_kmers + (uint64_t)k - 2u) >> 4;
+            uint32_t any = 0;
+            for (uint64_t c = c0; c <= c1; c++) any |= inval[c];
+            d.pad = any ? 1u : 0u;
+        }
         desc[r] = d;
         if (d.n_kmers > 0 && (uint32_t)d.n_kmers > mx) mx = (uint32_t)d.n_kmers;
     }
@@ -1090,18 +1101,18 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             if (rr < b.n) {
                 const KidReadDesc d = static_cast<const KidReadDesc *>(rare->desc)[rr];
                 dv_lo = (uint32_t)d.first_base;
-                dv_hn = ((uint32_t)(d.first_base >> 32) & 0xFFFFu) | ((d.n_kmers > 0 ? (uint32_t)d.n_kmers : 0u) << 16);
+                dv_hn = ((uint32_t)(d.first_base >> 32) & 0xFFFFu) | ((d.n_kmers > 0 ? (uint32_t)d.n_kmers : 0u) << 16) | ((d.pad & 1u) << 31);
             }
         };
         auto issue_words = [&](const uint32_t idx, uint32_t &c, uint32_t &iv) {
-            const uint64_t w0 = (((uint64_t)((uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)idx) & 0xFFFFu) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)idx)) >> 4;
+            const uint32_t hn = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)idx); // [15:0] first_base >> 32, [30:16] n_kmers, [31] may hold a masked base
+            const uint64_t w0 = (((uint64_t)(hn & 0xFFFFu) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)idx)) >> 4;
 #ifdef KID_ABLATE_WORDS // timing experiment only: the packed words always come from the same few cache lines
             const uint32_t *const pc = b.codes + (w0 & 1023u);
             const uint16_t *const pi = b.inval + (w0 & 1023u);
 #else
             const uint32_t *const pc = b.codes + w0;
-            const uint16_t *const pi = b.inval + w0;
+            const uint16_t *const pi = (hn >> 31) ? b.inval + w0 : b.inval; // clean read: any cached line will do, the mask is not looked at
 #endif
             asm volatile("global_load_dword %0, %1, %2" : "=v"(c) : "v"(lane4), "s"(pc) : "memory");
             asm volatile("global_load_ushort %0, %1, %2" : "=v"(iv) : "v"(lane4 >> 1), "s"(pi) : "memory");
@@ -1123,14 +1134,15 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             // ahead (a trip is one read here).
             auto duo = [&](const uint32_t i, uint32_t &cC, uint32_t &iC) { // (cC, iC): the word set that holds read i
                 const uint32_t ia = i - blk;
-                const uint32_t nk = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)ia) >> 16;
+                const uint32_t hnC = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)ia);
+                const uint32_t nk = (hnC >> 16) & 0x7FFFu;
                 const uint32_t sh = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)ia) & 15u;
                 const uint32_t nb = nk + (uint32_t)k - 1;
                 KidGroup<U> gA, gB;
                 uint32_t bad = 0;
                 if (ia + 2u > 63u) { blk = i + 1u; load_block(); } // (this read's descriptor is in scalars by now)
                 asm volatile("s_waitcnt vmcnt(2)" : "+v"(cC), "+v"(iC) : : "memory"); // behind: the words of the next read (other set)
-                const bool cl = (__ballot(iC != 0) == 0);
+                const bool cl = !(hnC >> 31) || (__ballot(iC != 0) == 0);
                 group_front(nullptr, sh, nb, nk, 0u, cl, gA, bad, false, cC, iC);
                 kid_u4 hA0 = issue_header(gA, 0), hA1 = issue_header(gA, 1);
                 group_front(nullptr, sh, nb, nk, (uint32_t)(U * 64), cl, gB, bad, false, cC, iC);
@@ -1163,8 +1175,8 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         } else {
         for (uint32_t i = 0; i < cnt; i += 2) {
             const uint32_t ia = i - blk;
-            const uint32_t nkA = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)ia) >> 16;
-            const uint32_t nkB = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)(ia + 1u)) >> 16;
+            const uint32_t hnA = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)ia), hnB = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)(ia + 1u));
+            const uint32_t nkA = (hnA >> 16) & 0x7FFFu, nkB = (hnB >> 16) & 0x7FFFu;
             const uint32_t shA = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)ia) & 15u;
             const uint32_t shB = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)(ia + 1u)) & 15u;
             KidGroup<U> gA, gB;
@@ -1176,7 +1188,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             // trip ahead: they come from HBM (the packed image of a batch is larger than the L2).
             asm volatile("s_waitcnt vmcnt(2)" : "+v"(cA), "+v"(iA) : : "memory"); // behind: the words of B
             KID_TICK(0);
-            const bool clA = (__ballot(iA != 0) == 0); // no base of the read resets a window
+            const bool clA = !(hnA >> 31) || (__ballot(iA != 0) == 0); // no base of the read resets a window
             group_front(nullptr, shA, nkA + (uint32_t)k - 1, nkA, 0u, clA, gA, badA, false, cA, iA);
             kid_u4 hA0 = issue_header(gA, 0), hA1 = issue_header(gA, 1);
             issue_words(i + 2u - blk, cA, iA);
@@ -1184,7 +1196,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
 
             asm volatile("s_waitcnt vmcnt(4)" : "+v"(cB), "+v"(iB) : : "memory"); // behind: headers of A, next words of A
             KID_TICK(2);
-            const bool clB = (__ballot(iB != 0) == 0);
+            const bool clB = !(hnB >> 31) || (__ballot(iB != 0) == 0);
             group_front(nullptr, shB, nkB + (uint32_t)k - 1, nkB, 0u, clB, gB, badB, false, cB, iB);
             kid_u4 hB0 = issue_header(gB, 0), hB1 = issue_header(gB, 1);
             issue_words(i + 3u - blk, cB, iB);
