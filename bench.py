@@ -35,6 +35,10 @@ from kmer_id_amd.dist import merge_sample  # noqa: E402
 
 K = 30
 READ_LEN = 150
+# BASELINE.json configs: [1] 1 M pairs per step (the configuration the metric is quoted on), [2] 100 M pairs in one
+# sample (the roofline run): one step = one batch = kid_classify_fixed_device over the whole resident read set
+CONFIGS = {"1m": {"pairs": 1_000_000, "steps": 10, "warmup": 2, "batches": 4},
+           "roofline100m": {"pairs": 100_000_000, "steps": 2, "warmup": 1, "batches": 1}}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -78,9 +82,18 @@ def gen_reads(device, cum, parent, r0, n_reads):
     return buf
 
 
-def cpu_baseline(host_keys, parent, cum, log2_slots, n_reads):
-    """The oracle (plain-C restatement of the reference's loop, 24-byte cells, one thread) on the
-    first n_reads reads of the same workload, same DB, on this host's cores."""
+def host_cores():
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:  # pragma: no cover
+        return max(1, os.cpu_count() or 1)
+
+
+def cpu_baseline(host_keys, parent, cum, log2_slots, n_reads, threads):
+    """The oracle (plain-C restatement of the reference's loop, 24-byte cells) on the first n_reads
+    reads of the same workload, same DB, on this host's cores: one thread (what the reference is), then
+    `threads` threads over contiguous read ranges with one shared table (counters merged the way the
+    reference's globals would have ended up: gcount adds, kmer_seen is a union)."""
     from oracle import binding as ob
     keys, targets = host_keys
     t0 = time.time()
@@ -96,39 +109,64 @@ def cpu_baseline(host_keys, parent, cum, log2_slots, n_reads):
     sec = os_.classify_timed(bases, off)
     st = os_.stats()
     g, u = os_.counts()
+    # all cores: a sample `threads` times as large would be fairer to the threads, but the comparison with the
+    # GPU's counters below wants the same reads; the merge of the per-thread sets is inside the timed region
+    sec_mt, gm, um, st_mt = odb.classify_mt(bases, off, threads)
     odb.close()
-    return {"value": (n_reads / 2) / sec, "unit": "paired reads/s", "cores": 1, "kind": "port",
-            "sample": "first %d reads (%d pairs) of the same synthetic stream, oracle/kmer_oracle.c, 1 thread, "
-                      "same %d-key DB in a 2^%d-cell table of 24-byte cells; %.1f s classify, %.1f s table build; "
-                      "%.2f M lookups/s" % (n_reads, n_reads // 2, keys.size, log2_slots, sec, build_s, st["lookups"] / sec / 1e6)}, (g, u)
+    if not (np.array_equal(gm, g) and np.array_equal(um, u)):
+        raise SystemExit("oracle: %d threads and 1 thread disagree" % threads)
+    return {"value": (n_reads / 2) / sec_mt, "unit": "paired reads/s", "cores": threads, "kind": "port",
+            "value_1_thread": (n_reads / 2) / sec, "lookups_per_s_1_thread": st["lookups"] / sec,
+            "lookups_per_s": st_mt["lookups"] / sec_mt,
+            "sample": "first %d reads (%d pairs) of the same synthetic stream, oracle/kmer_oracle.c (plain-C port of "
+                      "newkmer_10nx.cpp:452-617), same %d-key DB in a 2^%d-cell table of 24-byte cells; 1 thread: %.2f s "
+                      "classify (%.2f M lookups/s); %d threads, shared table, counters merged: %.2f s (%.2f M lookups/s); "
+                      "%.1f s table build" % (n_reads, n_reads // 2, keys.size, log2_slots, sec, st["lookups"] / sec / 1e6,
+                                              threads, sec_mt, st_mt["lookups"] / sec_mt / 1e6, build_s)}, (g, u)
+
+
+PMC_PROFILES = {"1m": ["profiles/r02/pmc_final.json", "profiles/r01/pmc_final.json"],
+                "roofline100m": ["profiles/r02/pmc_100m.json"]}
 
 
 def traffic_from_profile(args, info):
     """HBM bytes per classify launch from the committed rocprofv3 counter passes (profiles/):
     TCC_EA0_RDREQ_128B x 128 B + 64-byte requests + WRITE_SIZE.  Only reported when the profile
-    was taken on this exact workload; the live run does not collect counters."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_final.json")
-    if (not os.path.exists(path) or args.scale != 1.0 or args.pairs != 1_000_000 or args.log2_slots != 30 or
+    was taken on this exact workload; the live run does not collect counters (rocprofv3 --pmc is a
+    separate pass over the same command).  -> (bytes or None, where it came from)"""
+    if (args.scale != 1.0 or args.pairs != CONFIGS[args.config]["pairs"] or args.log2_slots != 30 or
             args.geometry != "minloc" or args.read_len != 150):
-        return None
-    try:
-        d = json.load(open(path))
-        rd = d["TCC_EA0_RDREQ_128B_sum"]["avg"] * 128 + d["TCC_EA0_RDREQ_64B_sum"]["avg"] * 64 + d["TCC_EA0_RDREQ_32B_sum"]["avg"] * 32
-        return rd + d["WRITE_SIZE"]["avg"] * 1024
-    except Exception:
-        return None
+        return None, "none: not the profiled workload"
+    for rel in PMC_PROFILES.get(args.config, []):
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        try:
+            d = json.load(open(path))
+            rd = d["TCC_EA0_RDREQ_128B_sum"]["avg"] * 128 + d["TCC_EA0_RDREQ_64B_sum"]["avg"] * 64 + d["TCC_EA0_RDREQ_32B_sum"]["avg"] * 32
+            return rd + d["WRITE_SIZE"]["avg"] * 1024, ("committed counter profile %s (rocprofv3 --pmc passes of this command on an "
+                                                        "earlier run; not collected live)" % rel)
+        except Exception:
+            continue
+    return None, "none: no committed counter profile for this workload"
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per rank per step (configs[1]: 1M pairs)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="1m",
+                    help="1m: BASELINE configs[1], 1 M pairs per step; roofline100m: configs[2], 100 M pairs resident, one batch per step")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--pairs", type=int, default=None, help="read pairs per rank per step (default: the config's)")
     ap.add_argument("--scale", type=float, default=1.0, help="DB scale (1.0 = 108.6 M k-mers)")
     ap.add_argument("--log2-slots", type=int, default=30)
     ap.add_argument("--cpu-reads", type=int, default=300_000, help="reads of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--batches", type=int, default=4, help="distinct resident read batches cycled over the steps")
+    ap.add_argument("--batches", type=int, default=None, help="distinct resident read batches cycled over the steps")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline leg (0 = every core of this host)")
+    ap.add_argument("--verify-ranks", type=int, default=1,
+                    help="N > 1: rank 0 re-classifies every rank's reads on its own table after the timed region and compares "
+                         "the merged counters with that single-table result")
     ap.add_argument("--gather", type=int, default=1, help="also measure the random 16-byte gather ceiling")
     ap.add_argument("--read-len", type=int, default=150, help="read length (configs[1]: 150; configs[4]: 250)")
     ap.add_argument("--geometry", choices=["minloc", "ref"], default="minloc",
@@ -139,6 +177,9 @@ def main():
                     help="classify the first batch on a second table built with the reference's geometry too: "
                          "full-size parity of the two placements + the reference-geometry probe count")
     args = ap.parse_args()
+    for k_, v_ in CONFIGS[args.config].items():
+        if getattr(args, k_) is None:
+            setattr(args, k_, v_)
     global READ_LEN
     READ_LEN = args.read_len
 
@@ -267,8 +308,9 @@ def main():
 
     cpu = None
     if want_cpu:
-        log("CPU baseline: oracle, 1 thread, %d reads ..." % args.cpu_reads)
-        cpu, (cg, cu) = cpu_baseline(host_keys, parent, cum, args.log2_slots, args.cpu_reads)
+        threads = args.cpu_threads or host_cores()
+        log("CPU baseline: oracle, 1 thread and %d threads, %d reads ..." % (threads, args.cpu_reads))
+        cpu, (cg, cu) = cpu_baseline(host_keys, parent, cum, args.log2_slots, args.cpu_reads, threads)
         # the same reads through the GPU path must give the same counts
         chk = db.sample()
         hb = synth.reads(cum, parent, args.cpu_reads, READ_LEN, K)
@@ -277,7 +319,28 @@ def main():
         cpu["gpu_equals_cpu_on_sample"] = bool(np.array_equal(gg, cg) and np.array_equal(gu, cu))
         chk.close()
 
+    # N > 1: the merged counters against ONE table that saw every rank's reads (rank 0's; untimed)
+    ranks_verified = None
+    if world > 1 and args.verify_ranks:
+        if rank == 0:
+            chk = db.sample()
+            for r in range(world):
+                rb = [gen_reads(device, cum, parent, (r * nb + b_) * n_reads, n_reads) for b_ in range(nb)] if r else batches
+                for i in range(args.steps):
+                    chk.classify_fixed_device(rb[i % nb].data_ptr(), READ_LEN, n_reads, stream=stream.cuda_stream)
+                torch.cuda.synchronize(device)
+                if r:
+                    del rb
+            g1, u1 = chk.end()
+            chk.close()
+            ranks_verified = bool(np.array_equal(g1, g) and np.array_equal(u1, u))
+            log("merged counters of %d ranks vs one table over all their reads: %s" % (world, "identical" if ranks_verified else "MISMATCH"))
+        dist.barrier()
+        if rank == 0 and not ranks_verified:
+            raise SystemExit("multi-rank merge disagrees with the single-table result")
+
     if rank == 0:
+        traffic, traffic_source = traffic_from_profile(args, info)
         pairs_total = args.steps * args.pairs * world
         line = {
             "metric": "paired reads classified/sec on bact10 DB",
@@ -295,10 +358,11 @@ def main():
             "config": {"workload": "bact10-synth DB (%d 30-mers on the real bact10 taxonomy, 2^%d-cell table resident in HBM), "
                                    "%d synthetic %d bp read pairs per GPU per step, reads resident in HBM" % (
                                        info.n_entries, args.log2_slots, args.pairs, READ_LEN),
-                       "db_scale": args.scale, "pairs_per_gpu_per_step": args.pairs, "read_len": READ_LEN, "k": K,
+                       "name": args.config, "db_scale": args.scale, "pairs_per_gpu_per_step": args.pairs, "read_len": READ_LEN, "k": K,
+                       "merged_counters_equal_single_table": ranks_verified,
                        "sharding": "reads sharded over %d rank(s), DB replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic_from_profile(args, info),
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "kid_classify_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "avg_kernel_ms_device_clock": (dev_ms / dev_launches) if dev_launches else None,
                          "kernel_time_source": "HIP events on the launch stream around the batch's kid_classify_kernel launches "

@@ -79,7 +79,9 @@ int kid_device_count(int *count);
  *                        order, exactly what process_kmer (:619-661) hands to
  *                        add_kmer; duplicates allowed, first one wins on lookup.
  *   parent[ntar]         Tree1::parent after all add_edge calls (default 1 = root).
- *   k                    KSIZE (1..31);  log2_slots  log2(MAXHASH) (6..34)
+ *   k                    KSIZE (1..31);  log2_slots  log2(MAXHASH) (6..32: slot indices are 32-bit)
+ *   n                    at most 2^32-2 entries and at most 2^log2_slots - 32 (KID_ERR_TABLE_FULL beyond, like
+ *                        the reference); the minimizer-localised placement is used while n <= 80 % of the cells
  *   max_probes           0 or the MAXREPROBE of kmer_read_m3.cpp
  *   device               HIP device ordinal
  * Table cells are 16 B {u64 key, u32 target, u32 insertion ordinal+1}.           */
@@ -96,6 +98,9 @@ void kid_db_destroy(kid_db *db);
 /* Hashtable::getHash (newkmer_10nx.cpp:204-233) for a batch of keys, on the GPU.
  * probes (nullable) receives the number of cells each lookup read. */
 int kid_db_lookup(kid_db *db, const uint64_t *keys, uint64_t n, uint32_t *targets, uint32_t *probes);
+/* Hashtable::integerHash (newkmer_10nx.cpp:189-197, MurmurHash3 fmix64) for a batch of keys, computed by the
+ * device code that places and finds the cells of the reference geometry. */
+int kid_hash_keys(int device, const uint64_t *keys, uint64_t n, uint64_t *out);
 /* Tree1::msca (newkmer_10nx.cpp:118-144) for a batch of (x,y), on the GPU. */
 int kid_db_msca(kid_db *db, const int32_t *x, const int32_t *y, uint64_t n, int32_t *out);
 
@@ -114,7 +119,7 @@ void kid_sample_destroy(kid_sample *s);
  *             (:714-760); pass NULL/NULL for whole reads (the FASTA callers, :851)
  *   out_final_targ  nullable; receives process_read's return value per read
  * Side effects on the sample: gcount[final_targ]++ per read (:613), and every
- * k-mer hit with target > 1 marks its table cell as seen (:596-603).
+ * k-mer hit with target > 1 marks its DB entry as seen (:596-603).
  * Reads are independent; results do not depend on batch boundaries.  A batch
  * holds at most 2^31-1 reads (KID_ERR_ARG beyond; split the batch).           */
 int kid_classify_batch(kid_sample *s, const uint8_t *bases, const uint64_t *offsets,
@@ -157,14 +162,18 @@ int kid_sample_kernel_time_device(kid_sample *s, double *total_ms, uint64_t *lau
 
 /* ---- multi-GPU merge helpers (reads sharded over ranks, DB replicated) ---------
  * ucount is |distinct DB k-mers hit| and is not additive over shards: ranks
- * exchange slices of the per-cell "seen" bitmap, OR them, and count their slice. */
+ * exchange slices of the "seen" bitmap, OR them, and count their slice.  The bitmap
+ * has one bit per DB ENTRY: bit o = "the key whose first insert was entry o (the o-th
+ * (key, target) pair handed to kid_db_build) was hit".  It does not depend on where the
+ * builder placed the cells, so bitmaps of samples on different kid_db objects built
+ * from the same entries (one per GPU, either placement) can be OR-ed.              */
 int kid_sample_seen_bytes(const kid_sample *s, uint64_t *nbytes);
 int kid_sample_seen_export(kid_sample *s, uint64_t byte_off, uint64_t nbytes, void *dst, int dst_on_device);
 int kid_sample_seen_or(kid_sample *s, uint64_t byte_off, uint64_t nbytes, const void *src, int src_on_device);
 int kid_sample_gcount(kid_sample *s, int64_t *gcount);
-/* ucount contribution of the table cells [slot_begin, slot_end) (multiples of 128; byte ranges of
- * the bitmap helpers above are multiples of 16) */
-int kid_sample_ucount_range(kid_sample *s, uint64_t slot_begin, uint64_t slot_end, int64_t *ucount);
+/* ucount contribution of the bitmap bits (entry ordinals) [bit_begin, bit_end): multiples of 128, at most
+ * 8 * kid_sample_seen_bytes (byte ranges of the bitmap helpers above are multiples of 16) */
+int kid_sample_ucount_range(kid_sample *s, uint64_t bit_begin, uint64_t bit_end, int64_t *ucount);
 
 /* ---- synthetic workload generators (bench + tests; deterministic, seeded) ------
  * DB key j = canonical(splitmix64(seed + j) mod 4^k); target of key j follows

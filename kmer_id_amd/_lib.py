@@ -39,6 +39,7 @@ PROTOTYPES = {
     "kid_db_get_info": (C.c_int, [C.c_void_p, C.POINTER(KidDbInfo)]),
     "kid_db_destroy": (None, [C.c_void_p]),
     "kid_db_lookup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "kid_hash_keys": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]),
     "kid_db_msca": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "kid_sample_begin": (C.c_int, [C.c_void_p, c_void_pp]),
     "kid_sample_reset": (C.c_int, [C.c_void_p]),

@@ -22,6 +22,15 @@ def _as(a, dtype):
     return a
 
 
+def hash_keys(keys, device=0):
+    """Hashtable::integerHash (fmix64) of every key, computed on the GPU."""
+    lib = _lib.load()
+    keys = _as(keys, np.uint64)
+    out = np.empty(keys.size, np.uint64)
+    check(lib.kid_hash_keys(device, _ptr(keys), keys.size, _ptr(out)))
+    return out
+
+
 class KmerDB:
     """Replaces `new Hashtable()` + `new Tree1()` + the add_kmer/add_edge load loops."""
 

@@ -35,6 +35,26 @@ static int kid_fail(int status, const char *fmt, ...)
                             hipGetErrorString(e_), __FILE__, __LINE__);                                            \
     } while (0)
 
+// temporaries of the unit entry points: freed on every exit path, KID_HIP's early returns included
+struct KidDevBuf {
+    void *p = nullptr;
+    KidDevBuf() {}
+    KidDevBuf(const KidDevBuf &) = delete;
+    KidDevBuf &operator=(const KidDevBuf &) = delete;
+    ~KidDevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t nbytes) { return hipMalloc(&p, nbytes ? nbytes : 16); }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+struct KidEvent {
+    hipEvent_t e = nullptr;
+    KidEvent() {}
+    KidEvent(const KidEvent &) = delete;
+    KidEvent &operator=(const KidEvent &) = delete;
+    ~KidEvent() { if (e) hipEventDestroy(e); }
+    hipError_t create() { return hipEventCreate(&e); }
+    hipEvent_t release() { hipEvent_t r = e; e = nullptr; return r; }
+};
+
 struct kid_db {
     int device = 0;
     int num_cu = 0;
@@ -43,6 +63,8 @@ struct kid_db {
     uint4 *rows = nullptr;
     int32_t *parent = nullptr;
     int32_t *depth = nullptr;
+    uint32_t *ord_target = nullptr; // target of entry o as handed to the builder, padded with zeros to a multiple of 128
+    uint64_t seen_bits = 0;         // entries rounded up to whole 16-byte groups of the seen-bitmap
     kid_db_info info{};
 };
 
@@ -61,6 +83,10 @@ struct kid_sample {
     KidRareArgs *d_rare = nullptr; // device copy, written once in kid_sample_begin (batch_max: by every batch)
     uint32_t batch_seq = 0;
     uint64_t reads_submitted = 0; // since the last reset: checked against the device's count when results are read
+    // the scratch below is one set per sample: batches on different streams are ordered behind each other
+    hipStream_t last_stream = nullptr;
+    bool has_last_stream = false;
+    hipEvent_t order_ev = nullptr;
     KidReadDesc *sc_desc = nullptr;
     uint64_t sc_desc_cap = 0;
     uint32_t *sc_codes = nullptr;
@@ -248,6 +274,17 @@ static int kid_db_build_common(const uint64_t *h_keys, const uint32_t *h_targets
 
     const uint64_t table_bytes = nslots * sizeof(uint4);
     KID_DB_HIP(hipMalloc(&db->table, table_bytes));
+    // the per-sample seen-bitmap has one bit per ENTRY (its insertion ordinal, cell word 3), not per cell: a key's bit
+    // is then the same in every table built from the same entries, whatever the cell placement -- what lets samples of
+    // different GPUs (each with its own replica of the table) be OR-ed.  ord_target maps a bit back to its target.
+    db->seen_bits = ((n + 127) / 128) * 128;
+    if (db->seen_bits == 0) db->seen_bits = 128;
+    KID_DB_HIP(hipMalloc(&db->ord_target, db->seen_bits * 4));
+    KID_DB_HIP(hipMemset(db->ord_target, 0, db->seen_bits * 4));
+    if (n > 0) {
+        if (h_targets) KID_DB_HIP(hipMemcpy(db->ord_target, h_targets, n * 4, hipMemcpyHostToDevice));
+        else KID_DB_HIP(hipMemcpy(db->ord_target, d_targets_in, n * 4, hipMemcpyDeviceToDevice));
+    }
     KID_DB_HIP(hipMalloc(&db->parent, sizeof(int32_t) * (size_t)ntar));
     KID_DB_HIP(hipMalloc(&db->depth, sizeof(int32_t) * (size_t)ntar));
     KID_DB_HIP(hipMemcpy(db->parent, par.data(), sizeof(int32_t) * (size_t)ntar, hipMemcpyHostToDevice));
@@ -290,20 +327,20 @@ static int kid_db_build_common(const uint64_t *h_keys, const uint32_t *h_targets
         KID_DB_HIP(hipMemset(db->table, 0, table_bytes));
         if (n > 0) {
             uint64_t *dk = nullptr;
-            uint32_t *dt = nullptr;
             const uint64_t *dkc = (const uint64_t *)d_keys_in;
-            const uint32_t *dtc = (const uint32_t *)d_targets_in;
+            const uint32_t *dtc = db->ord_target;
             if (!dkc) {
                 KID_DB_HIP(hipMalloc(&dk, n * 8));
-                hipError_t e = hipMalloc(&dt, n * 4);
+                hipError_t e = hipMemcpy(dk, h_keys, n * 8, hipMemcpyHostToDevice);
                 if (e != hipSuccess) { hipFree(dk); KID_DB_HIP(e); }
-                KID_DB_HIP(hipMemcpy(dk, h_keys, n * 8, hipMemcpyHostToDevice));
-                KID_DB_HIP(hipMemcpy(dt, h_targets, n * 4, hipMemcpyHostToDevice));
-                dkc = dk; dtc = dt;
+                dkc = dk;
             }
             unsigned long long *d_occ = nullptr;
-            KID_DB_HIP(hipMalloc(&d_occ, 16));
-            KID_DB_HIP(hipMemset(d_occ, 0, 16));
+            {
+                hipError_t e = hipMalloc(&d_occ, 16);
+                if (e == hipSuccess) e = hipMemset(d_occ, 0, 16);
+                if (e != hipSuccess) { if (d_occ) hipFree(d_occ); if (dk) hipFree(dk); KID_DB_HIP(e); }
+            }
             const int grid = kid_grid_for(n, 256, db->num_cu * 16);
             hipLaunchKernelGGL(kid_build_insert_kernel, dim3(grid), dim3(256), 0, 0, db->table, (uint32_t)(nslots - 1), dkc,
                                dtc, n, (uint32_t)ntar, d_occ, k, minloc, line_shift, line_mask);
@@ -314,7 +351,6 @@ static int kid_db_build_common(const uint64_t *h_keys, const uint32_t *h_targets
             if (e == hipSuccess) e = hipMemcpy(occ, d_occ, 16, hipMemcpyDeviceToHost);
             hipFree(d_occ);
             if (dk) hipFree(dk);
-            if (dt) hipFree(dt);
             KID_DB_HIP(e);
             if (occ[1] != 0) { kid_db_destroy(db); return kid_fail(KID_ERR_TARGET, "%llu targets >= ntar", occ[1]); }
             n_occupied = occ[0];
@@ -379,6 +415,7 @@ extern "C" void kid_db_destroy(kid_db *db)
     if (db->rows) hipFree(db->rows);
     if (db->parent) hipFree(db->parent);
     if (db->depth) hipFree(db->depth);
+    if (db->ord_target) hipFree(db->ord_target);
     delete db;
 }
 
@@ -388,17 +425,32 @@ extern "C" int kid_db_lookup(kid_db *db, const uint64_t *keys, uint64_t n, uint3
     int rc = kid_use_device(db->device);
     if (rc != KID_OK) return rc;
     if (n == 0) return KID_OK;
-    uint64_t *dk = nullptr;
-    uint32_t *dt = nullptr, *dp = nullptr;
-    KID_HIP(hipMalloc(&dk, n * 8));
-    KID_HIP(hipMalloc(&dt, n * 4));
-    if (probes) KID_HIP(hipMalloc(&dp, n * 4));
-    KID_HIP(hipMemcpy(dk, keys, n * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(kid_lookup_kernel, dim3(kid_grid_for(n, 256, db->num_cu * 16)), dim3(256), 0, 0, db->d, dk, n, dt, dp);
+    KidDevBuf dk, dt, dp;
+    KID_HIP(dk.alloc(n * 8));
+    KID_HIP(dt.alloc(n * 4));
+    if (probes) KID_HIP(dp.alloc(n * 4));
+    KID_HIP(hipMemcpy(dk.p, keys, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kid_lookup_kernel, dim3(kid_grid_for(n, 256, db->num_cu * 16)), dim3(256), 0, 0, db->d, dk.as<uint64_t>(), n,
+                       dt.as<uint32_t>(), dp.as<uint32_t>());
     KID_HIP(hipDeviceSynchronize());
-    KID_HIP(hipMemcpy(targets, dt, n * 4, hipMemcpyDeviceToHost));
-    if (probes) KID_HIP(hipMemcpy(probes, dp, n * 4, hipMemcpyDeviceToHost));
-    hipFree(dk); hipFree(dt); if (dp) hipFree(dp);
+    KID_HIP(hipMemcpy(targets, dt.p, n * 4, hipMemcpyDeviceToHost));
+    if (probes) KID_HIP(hipMemcpy(probes, dp.p, n * 4, hipMemcpyDeviceToHost));
+    return KID_OK;
+}
+
+extern "C" int kid_hash_keys(int device, const uint64_t *keys, uint64_t n, uint64_t *out)
+{
+    if (n && (!keys || !out)) return kid_fail(KID_ERR_ARG, "null argument");
+    int rc = kid_use_device(device);
+    if (rc != KID_OK) return rc;
+    if (n == 0) return KID_OK;
+    KidDevBuf dk, dout;
+    KID_HIP(dk.alloc(n * 8));
+    KID_HIP(dout.alloc(n * 8));
+    KID_HIP(hipMemcpy(dk.p, keys, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kid_fmix_kernel, dim3(kid_grid_for(n, 256, 4096)), dim3(256), 0, 0, dk.as<uint64_t>(), n, dout.as<uint64_t>());
+    KID_HIP(hipDeviceSynchronize());
+    KID_HIP(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost));
     return KID_OK;
 }
 
@@ -411,16 +463,16 @@ extern "C" int kid_db_msca(kid_db *db, const int32_t *x, const int32_t *y, uint6
     int rc = kid_use_device(db->device);
     if (rc != KID_OK) return rc;
     if (n == 0) return KID_OK;
-    int32_t *dx = nullptr, *dy = nullptr, *dout = nullptr;
-    KID_HIP(hipMalloc(&dx, n * 4));
-    KID_HIP(hipMalloc(&dy, n * 4));
-    KID_HIP(hipMalloc(&dout, n * 4));
-    KID_HIP(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
-    KID_HIP(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(kid_msca_kernel, dim3(kid_grid_for(n, 256, db->num_cu * 16)), dim3(256), 0, 0, db->d, dx, dy, n, dout);
+    KidDevBuf dx, dy, dout;
+    KID_HIP(dx.alloc(n * 4));
+    KID_HIP(dy.alloc(n * 4));
+    KID_HIP(dout.alloc(n * 4));
+    KID_HIP(hipMemcpy(dx.p, x, n * 4, hipMemcpyHostToDevice));
+    KID_HIP(hipMemcpy(dy.p, y, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kid_msca_kernel, dim3(kid_grid_for(n, 256, db->num_cu * 16)), dim3(256), 0, 0, db->d, dx.as<int32_t>(),
+                       dy.as<int32_t>(), n, dout.as<int32_t>());
     KID_HIP(hipDeviceSynchronize());
-    KID_HIP(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
-    hipFree(dx); hipFree(dy); hipFree(dout);
+    KID_HIP(hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost));
     return KID_OK;
 }
 
@@ -435,6 +487,7 @@ extern "C" void kid_sample_destroy(kid_sample *s)
     if (s->seen) hipFree(s->seen);
     for (auto &ev : s->timed) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     if (s->d_rare) hipFree(s->d_rare);
+    if (s->order_ev) hipEventDestroy(s->order_ev);
     if (s->sc_desc) hipFree(s->sc_desc);
     if (s->sc_codes) hipFree(s->sc_codes);
     if (s->sc_inval) hipFree(s->sc_inval);
@@ -472,7 +525,7 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
     kid_sample *s = new kid_sample();
     s->db = db;
     const size_t nt = (size_t)db->info.ntar;
-    s->seen_words = ((db->d.nslots + 127) / 128) * 4; // whole 16-byte groups (128 cells)
+    s->seen_words = db->seen_bits / 32; // one bit per DB entry, whole 16-byte groups
 #define KID_S_HIP(call)                                                                                           \
     do {                                                                                                          \
         hipError_t e_ = (call);                                                                                   \
@@ -512,6 +565,16 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     if (b.n > 0x7FFFFFFFull) return kid_fail(KID_ERR_ARG, "at most 2^31-1 reads per batch");
     if (bases_nbytes >> 48) return kid_fail(KID_ERR_ARG, "a batch of 2^48 bytes or more");
     const uint64_t nchunks = (bases_nbytes + 15) / 16;
+    // All batches of a sample share its scratch (descriptors, packed image, the device argument block): a batch
+    // issued on another stream than the one before is made to wait for it (or for the resize below, the device).
+    if (s->has_last_stream && s->last_stream != stream) {
+        if (!s->order_ev) KID_HIP(hipEventCreateWithFlags(&s->order_ev, hipEventDisableTiming));
+        KID_HIP(hipEventRecord(s->order_ev, s->last_stream));
+        KID_HIP(hipStreamWaitEvent(stream, s->order_ev, 0));
+    }
+    s->last_stream = stream;
+    s->has_last_stream = true;
+    if (b.n > s->sc_desc_cap || nchunks > s->sc_chunks_cap) KID_HIP(hipDeviceSynchronize()); // (scratch in use is not freed)
     if (b.n > s->sc_desc_cap) {
         if (s->sc_desc) hipFree(s->sc_desc);
         s->sc_desc = nullptr; s->sc_desc_cap = 0;
@@ -531,28 +594,36 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
                            nchunks, db->d.u_is_t, s->sc_codes, s->sc_inval);
     hipLaunchKernelGGL(kid_prepare_kernel, dim3(kid_grid_for(b.n, 256, db->num_cu * 8)), dim3(256), 0, stream, b, db->info.k,
                        s->sc_desc, s->stats, s->d_rare, ++s->batch_seq, nchunks ? s->sc_inval : nullptr);
-    KidPacked pk{s->sc_codes, s->sc_inval, s->sc_desc, b.out_final, b.n};
     const int block = 512, wpb = block / 64;
     const uint32_t ntar = (uint32_t)db->info.ntar;
     // the gcount histogram lives in LDS while four workgroups per CU (160 KiB) still fit beside the waves' strips
     // and queues.  Minimizer-localised table: two 16-bit counters per word, so a workgroup must stay below 65536
-    // reads per launch.
+    // reads per launch -- a larger batch is classified in several launches of the same grid (`span` reads each).
     const bool ml = db->d.minloc != 0;
     const int grid = kid_grid_for(b.n, wpb, db->num_cu * 4);
-    const bool fits16 = b.n / (uint64_t)grid + wpb < 65536u;
     const uint32_t hist_words32 = (ntar + 3u) & ~3u, hist_words16 = ((ntar + 1u) / 2u + 3u) & ~3u;
     const uint32_t hist_words = ml ? hist_words16 : hist_words32;
     const uint32_t wave_words = ml ? KID_GEN_ML_LDS_WORDS : KID_WAVE_LDS_WORDS;
-    const bool hist = (hist_words + wpb * wave_words) * 4u <= 40u * 1024u && (!ml || fits16);
-    const bool hist_pair = (hist_words16 + wpb * KID_PAIR_LDS_WORDS) * 4u <= 40u * 1024u && fits16;
+    const bool hist = (hist_words + wpb * wave_words) * 4u <= 40u * 1024u;
+    const bool hist_pair = (hist_words16 + wpb * KID_PAIR_LDS_WORDS) * 4u <= 40u * 1024u;
+    uint64_t span = b.n;
+    if (ml && (hist || hist_pair)) {
+        const uint64_t cap = (uint64_t)grid * (65535u - 2u * (uint32_t)wpb); // reads per launch: < 65536 per workgroup
+        if (span > cap) span = cap;
+    }
     KidSampleDev sd{s->gcount, s->seen, s->stats};
     const bool rows = db->rows != nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    KidEvent ev0, ev1;
     if (s->timing) {
-        KID_HIP(hipEventCreate(&ev0));
-        KID_HIP(hipEventCreate(&ev1));
-        KID_HIP(hipEventRecord(ev0, stream));
+        KID_HIP(ev0.create());
+        KID_HIP(ev1.create());
+        KID_HIP(hipEventRecord(ev0.e, stream));
     }
+    for (uint64_t r0 = 0; r0 < b.n; r0 += span) {
+    const uint64_t cnt = b.n - r0 < span ? b.n - r0 : span;
+    KidPacked pk{s->sc_codes, s->sc_inval, s->sc_desc + r0, b.out_final ? b.out_final + r0 : nullptr, cnt};
+    if (r0 != 0) // the kernels find this launch's descriptors and result array in the sample's device struct
+        hipLaunchKernelGGL(kid_rebase_kernel, dim3(1), dim3(1), 0, stream, s->d_rare, pk.desc, pk.out_final);
 #define KID_LAUNCH1(R, H, M, KF, PK)                                                                                            \
     hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, KF, PK>), dim3(grid), dim3(block),                                     \
                        (((H) ? ((PK) ? hist_words16 : hist_words) : 0u) +                                                       \
@@ -597,9 +668,10 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
 #undef KID_LAUNCH_PK
 #undef KID_LAUNCH1
 #undef KID_LAUNCH
+    }
     if (s->timing) {
-        KID_HIP(hipEventRecord(ev1, stream));
-        s->timed.emplace_back(ev0, ev1);
+        KID_HIP(hipEventRecord(ev1.e, stream));
+        s->timed.emplace_back(ev0.release(), ev1.release());
         s->timed_batches++;
     }
     KID_HIP(hipGetLastError());
@@ -771,25 +843,22 @@ extern "C" int kid_trim_batch(kid_db *db, const uint8_t *quals, const uint64_t *
     int rc = kid_use_device(db->device);
     if (rc != KID_OK) return rc;
     const uint64_t base0 = offsets[0], nbytes = offsets[n_reads] - base0;
-    uint8_t *dq = nullptr, *dkeep = nullptr;
-    uint64_t *doff = nullptr;
-    int32_t *ds = nullptr, *de = nullptr;
+    KidDevBuf dq, dkeep, doff, ds, de;
     std::vector<uint64_t> rel(n_reads + 1);
     for (uint64_t r = 0; r <= n_reads; r++) rel[r] = offsets[r] - base0;
-    KID_HIP(hipMalloc(&dq, nbytes + 16));
-    KID_HIP(hipMalloc(&doff, (n_reads + 1) * 8));
-    KID_HIP(hipMalloc(&ds, n_reads * 4));
-    KID_HIP(hipMalloc(&de, n_reads * 4));
-    KID_HIP(hipMalloc(&dkeep, n_reads));
-    if (nbytes) KID_HIP(hipMemcpy(dq, quals + base0, nbytes, hipMemcpyHostToDevice));
-    KID_HIP(hipMemcpy(doff, rel.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(kid_trim_kernel, dim3(kid_grid_for(n_reads, 256, db->num_cu * 16)), dim3(256), 0, 0, dq, doff, n_reads,
-                       db->info.k, ds, de, dkeep);
+    KID_HIP(dq.alloc(nbytes + 16));
+    KID_HIP(doff.alloc((n_reads + 1) * 8));
+    KID_HIP(ds.alloc(n_reads * 4));
+    KID_HIP(de.alloc(n_reads * 4));
+    KID_HIP(dkeep.alloc(n_reads));
+    if (nbytes) KID_HIP(hipMemcpy(dq.p, quals + base0, nbytes, hipMemcpyHostToDevice));
+    KID_HIP(hipMemcpy(doff.p, rel.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kid_trim_kernel, dim3(kid_grid_for(n_reads, 256, db->num_cu * 16)), dim3(256), 0, 0, dq.as<uint8_t>(),
+                       doff.as<uint64_t>(), n_reads, db->info.k, ds.as<int32_t>(), de.as<int32_t>(), dkeep.as<uint8_t>());
     KID_HIP(hipDeviceSynchronize());
-    KID_HIP(hipMemcpy(start, ds, n_reads * 4, hipMemcpyDeviceToHost));
-    KID_HIP(hipMemcpy(stop, de, n_reads * 4, hipMemcpyDeviceToHost));
-    KID_HIP(hipMemcpy(keep, dkeep, n_reads, hipMemcpyDeviceToHost));
-    hipFree(dq); hipFree(doff); hipFree(ds); hipFree(de); hipFree(dkeep);
+    KID_HIP(hipMemcpy(start, ds.p, n_reads * 4, hipMemcpyDeviceToHost));
+    KID_HIP(hipMemcpy(stop, de.p, n_reads * 4, hipMemcpyDeviceToHost));
+    KID_HIP(hipMemcpy(keep, dkeep.p, n_reads, hipMemcpyDeviceToHost));
     return KID_OK;
 }
 
@@ -820,9 +889,8 @@ extern "C" int kid_sample_gcount(kid_sample *s, int64_t *gcount)
 extern "C" int kid_sample_ucount_range(kid_sample *s, uint64_t slot_begin, uint64_t slot_end, int64_t *ucount)
 {
     if (!s || !ucount) return kid_fail(KID_ERR_ARG, "null argument");
-    if (slot_end == s->db->d.nslots) slot_end = s->seen_words * 32; // tables smaller than one group: count the padding too (always 0)
     if (slot_begin > slot_end || slot_end > s->seen_words * 32 || (slot_begin & 127) || (slot_end & 127))
-        return kid_fail(KID_ERR_ARG, "slot range must be 128-aligned and inside the table");
+        return kid_fail(KID_ERR_ARG, "bit range must be 128-aligned and inside the bitmap");
     int rc = kid_use_device(s->db->device);
     if (rc != KID_OK) return rc;
     KID_HIP(hipDeviceSynchronize());
@@ -833,11 +901,11 @@ extern "C" int kid_sample_ucount_range(kid_sample *s, uint64_t slot_begin, uint6
         const uint32_t ntar = (uint32_t)s->db->info.ntar;
         const int ugrid = kid_grid_for((w1 - w0) / 4, 512, s->db->num_cu * 4);
         if (ntar * 4u <= 64u * 1024u)
-            hipLaunchKernelGGL((kid_ucount_kernel<true>), dim3(ugrid), dim3(512), ntar * 4u, 0, s->seen, w0, w1, s->db->table,
+            hipLaunchKernelGGL((kid_ucount_kernel<true>), dim3(ugrid), dim3(512), ntar * 4u, 0, s->seen, w0, w1, s->db->ord_target,
                                s->ucount, ntar);
         else
-            hipLaunchKernelGGL((kid_ucount_kernel<false>), dim3(ugrid), dim3(512), 0, 0, s->seen, w0, w1, s->db->table, s->ucount,
-                               ntar);
+            hipLaunchKernelGGL((kid_ucount_kernel<false>), dim3(ugrid), dim3(512), 0, 0, s->seen, w0, w1, s->db->ord_target,
+                               s->ucount, ntar);
         KID_HIP(hipGetLastError());
     }
     KID_HIP(hipDeviceSynchronize());
@@ -850,7 +918,7 @@ extern "C" int kid_sample_end(kid_sample *s, int64_t *gcount, int64_t *ucount)
     if (!s || !gcount || !ucount) return kid_fail(KID_ERR_ARG, "null argument");
     int rc = kid_sample_gcount(s, gcount);
     if (rc != KID_OK) return rc;
-    return kid_sample_ucount_range(s, 0, s->db->d.nslots, ucount);
+    return kid_sample_ucount_range(s, 0, s->seen_words * 32, ucount);
 }
 
 extern "C" int kid_sample_stats(kid_sample *s, uint64_t out[4])
@@ -903,17 +971,16 @@ extern "C" int kid_sample_seen_or(kid_sample *s, uint64_t byte_off, uint64_t nby
     if (rc != KID_OK) return rc;
     if (nbytes == 0) return KID_OK;
     const uint32_t *dsrc = (const uint32_t *)src;
-    uint32_t *tmp = nullptr;
+    KidDevBuf tmp;
     if (!src_on_device) {
-        KID_HIP(hipMalloc(&tmp, nbytes));
-        KID_HIP(hipMemcpy(tmp, src, nbytes, hipMemcpyHostToDevice));
-        dsrc = tmp;
+        KID_HIP(tmp.alloc(nbytes));
+        KID_HIP(hipMemcpy(tmp.p, src, nbytes, hipMemcpyHostToDevice));
+        dsrc = tmp.as<uint32_t>();
     }
     KID_HIP(hipDeviceSynchronize());
     hipLaunchKernelGGL(kid_or_kernel, dim3(kid_grid_for(nbytes / 4, 256, s->db->num_cu * 16)), dim3(256), 0, 0,
                        s->seen + byte_off / 4, dsrc, nbytes / 4);
     KID_HIP(hipDeviceSynchronize());
-    if (tmp) hipFree(tmp);
     return KID_OK;
 }
 
@@ -935,13 +1002,12 @@ extern "C" int kid_synth_db_keys_device(uint64_t seed, int k, const uint64_t *cu
     if (!cum_host || !d_keys || !d_targets || ntar < 1 || k < 1 || k > 31) return kid_fail(KID_ERR_ARG, "bad argument");
     int rc = kid_use_device(device);
     if (rc != KID_OK) return rc;
-    uint64_t *dcum = nullptr;
-    KID_HIP(hipMalloc(&dcum, ((size_t)ntar + 1) * 8));
-    KID_HIP(hipMemcpy(dcum, cum_host, ((size_t)ntar + 1) * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(kid_synth_keys_kernel, dim3(kid_grid_for(n, 256, 256 * 16)), dim3(256), 0, 0, seed, k, dcum, ntar, j0, n,
-                       (uint64_t *)d_keys, (uint32_t *)d_targets);
+    KidDevBuf dcum;
+    KID_HIP(dcum.alloc(((size_t)ntar + 1) * 8));
+    KID_HIP(hipMemcpy(dcum.p, cum_host, ((size_t)ntar + 1) * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kid_synth_keys_kernel, dim3(kid_grid_for(n, 256, 256 * 16)), dim3(256), 0, 0, seed, k, dcum.as<uint64_t>(),
+                       ntar, j0, n, (uint64_t *)d_keys, (uint32_t *)d_targets);
     KID_HIP(hipDeviceSynchronize());
-    hipFree(dcum);
     return KID_OK;
 }
 
@@ -962,16 +1028,14 @@ extern "C" int kid_synth_reads_device(uint64_t db_seed, uint64_t read_seed, int 
         return kid_fail(KID_ERR_ARG, "bad argument");
     int rc = kid_use_device(device);
     if (rc != KID_OK) return rc;
-    uint64_t *dcum = nullptr;
-    int32_t *dpar = nullptr;
-    KID_HIP(hipMalloc(&dcum, ((size_t)ntar + 1) * 8));
-    KID_HIP(hipMalloc(&dpar, (size_t)ntar * 4));
-    KID_HIP(hipMemcpy(dcum, cum_host, ((size_t)ntar + 1) * 8, hipMemcpyHostToDevice));
-    KID_HIP(hipMemcpy(dpar, parent_host, (size_t)ntar * 4, hipMemcpyHostToDevice));
+    KidDevBuf dcum, dpar;
+    KID_HIP(dcum.alloc(((size_t)ntar + 1) * 8));
+    KID_HIP(dpar.alloc((size_t)ntar * 4));
+    KID_HIP(hipMemcpy(dcum.p, cum_host, ((size_t)ntar + 1) * 8, hipMemcpyHostToDevice));
+    KID_HIP(hipMemcpy(dpar.p, parent_host, (size_t)ntar * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(kid_synth_reads_kernel, dim3(kid_grid_for(n_reads, 256, 256 * 16)), dim3(256), 0, 0, db_seed, read_seed, k,
-                       dcum, dpar, ntar, r0, n_reads, read_len, (uint8_t *)d_bases);
+                       dcum.as<uint64_t>(), dpar.as<int32_t>(), ntar, r0, n_reads, read_len, (uint8_t *)d_bases);
     KID_HIP(hipDeviceSynchronize());
-    hipFree(dcum); hipFree(dpar);
     return KID_OK;
 }
 
@@ -985,11 +1049,13 @@ extern "C" int kid_bench_gather(kid_db *db, uint64_t n_loads, int inflight, int 
     if (inflight != 1 && inflight != 2 && inflight != 4 && inflight != 8) return kid_fail(KID_ERR_ARG, "inflight must be 1,2,4 or 8");
     uint64_t rounds = n_loads / (lanes * (uint64_t)inflight);
     if (rounds < 1) rounds = 1;
-    uint32_t *sink = nullptr;
-    KID_HIP(hipMalloc(&sink, 16));
-    hipEvent_t e0, e1;
-    KID_HIP(hipEventCreate(&e0));
-    KID_HIP(hipEventCreate(&e1));
+    KidDevBuf sinkb;
+    KID_HIP(sinkb.alloc(16));
+    uint32_t *const sink = sinkb.as<uint32_t>();
+    KidEvent ev0, ev1;
+    KID_HIP(ev0.create());
+    KID_HIP(ev1.create());
+    const hipEvent_t e0 = ev0.e, e1 = ev1.e;
     auto launch = [&]() {
         switch (inflight) {
         case 1: hipLaunchKernelGGL((kid_gather_kernel<1>), dim3(grid), dim3(block), 0, 0, db->table, db->d.slot_mask, rounds, sink); break;
@@ -1006,7 +1072,6 @@ extern "C" int kid_bench_gather(kid_db *db, uint64_t n_loads, int inflight, int 
     KID_HIP(hipEventSynchronize(e1));
     float ms = 0;
     KID_HIP(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(sink);
     *ms_out = ms / (float)iters;
     *loads_out = rounds * lanes * (uint64_t)inflight; // loads actually issued per launch
     return KID_OK;

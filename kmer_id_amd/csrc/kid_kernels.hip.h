@@ -9,7 +9,8 @@
 //   rows    uint4[ntar]           8 x u16 per taxonomy node: e0 = depth, e[d] = ancestor of
 //                                 the node at depth d (d = 1..7, the node itself at d = depth)
 //   parent  int32[ntar], depth int32[ntar]   (fallback for trees deeper than 8 levels)
-//   seen    u32[2^log2_slots / 32]  one bit per table cell, per sample (-> ucount)
+//   seen    u32[n_entries / 32]     one bit per DB entry (insertion ordinal), per sample (-> ucount)
+//   ord_target u32[n_entries]       target of entry o (what the builder was handed)
 //   gcount  u64[ntar], stats u64[8] per sample
 #pragma once
 #include <hip/hip_runtime.h>
@@ -17,6 +18,7 @@
 #include "kid_common.h"
 
 #define KID_WAVE 64
+#define KID_TOMBSTONE_HI 0xFFFFFFFFu // high key word of a duplicate entry that lost to an earlier insert (keys are < 2^62)
 #define KID_SEG_KMERS 960  // k-mers per read segment: 960 + 30 bases + 15 alignment slack <= 64 chunks of 16 B
 #define KID_WAVE_LDS_WORDS 104 // per wave, general loops: 66 packed-base words + 34 invalid-mask words + 4 counters
 // pair kernel (no strips): 4 counters, the queue of unresolved lookups (3 words + 1 tag byte per entry) and the
@@ -173,7 +175,7 @@ __device__ __forceinline__ uint32_t kid_bucket_lookup(const KidDevDb &db, uint64
             m &= m - 1;
             const uint4 c = db.table[base + 1u + j];
             ncell++;
-            if (c.z != 0 && c.x == (uint32_t)key && c.y == (uint32_t)(key >> 32)) { slot = base + 1u + j; return c.z; }
+            if (c.z != 0 && c.x == (uint32_t)key && c.y == (uint32_t)(key >> 32)) { slot = c.w - 1u; return c.z; }
         }
         if (!kid_hdr_continues(h.w, fp)) return 0;
         line = (line + 1u) & db.line_mask;
@@ -192,7 +194,7 @@ __device__ __forceinline__ uint32_t kid_dev_lookup(const KidDevDb &db, uint64_t 
         reprobe += ++i;
         const uint4 c = db.table[idx];
         if (c.z == 0) break;
-        if (c.x == (uint32_t)key && c.y == (uint32_t)(key >> 32)) { res = c.z; slot = idx; break; }
+        if (c.x == (uint32_t)key && c.y == (uint32_t)(key >> 32)) { res = c.z; slot = c.w - 1u; break; }
     } while (reprobe < db.nslots && (db.max_probes == 0 || i < db.max_probes));
     nprobe = i;
     return res;
@@ -349,6 +351,13 @@ __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, u
     if (bad) atomicAdd(&stats[4], (unsigned long long)bad);
 }
 
+// a batch classified in several launches: the next launch's share of the descriptors and of the result array
+__global__ void kid_rebase_kernel(KidRareArgs *rare, const KidReadDesc *desc, uint32_t *out_final)
+{
+    rare->desc = desc;
+    rare->out_final = out_final;
+}
+
 // ASCII -> 2 bits per base + invalid mask for the whole batch buffer, 16 bases per lane
 __global__ void kid_pack_kernel(const uint8_t *bases, uint64_t nchunks, uint32_t u_is_t, uint32_t *codes, uint16_t *inval)
 {
@@ -403,6 +412,15 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         if (mode != PAIRK) return;
     }
     if (threadIdx.x == 0) atomicMin(&s.stats[30], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#if defined(KID_STAGGER) && KID_STAGGER > 0
+    // experiment: the waves of a SIMD start out of phase (1: the second half of a workgroup's waves half a trip
+    // later; 2: eight phases from wave number and workgroup), so that one wave's front half meets another's wait
+    if (PAIRK == 1) {
+        const uint32_t w8 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        uint32_t ph = (KID_STAGGER == 1) ? ((w8 >> 2) & 1u) * 4u : (((w8 >> 2) & 1u) * 4u + ((blockIdx.x * 0x9E3779B1u) >> 30));
+        for (uint32_t q = 0; q < ph * 3u; q++) __builtin_amdgcn_s_sleep(14); // 3 x 14 x 64 cycles = 1/8 of a ~21 k-cycle trip
+    }
+#endif
     // (descs == b.desc, passed once more as a restrict-qualified argument: the wave-uniform
     //  descriptor loads then become scalar loads, which stay in flight until first use)
     extern __shared__ uint32_t kid_smem[];
@@ -593,7 +611,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             for (int u = 0; u < U; u++) {
                 bool go = mm[u] != 0;
                 if (idx[u] && c[u].z != 0 && c[u].x == (uint32_t)g.key[u] && c[u].y == (uint32_t)(g.key[u] >> 32)) {
-                    tgt[u] = c[u].z; slot[u] = idx[u]; go = false;
+                    tgt[u] = c[u].z; slot[u] = c[u].w - 1u; go = false;
                 }
                 // leftovers (a second candidate: 1e-4 of the lookups; a chained line: 1e-5)
                 uint32_t ln = g.hlo[u], mu = m[u];
@@ -605,7 +623,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                         const uint32_t ix = ln * KID_LINE_CELLS + 1u + j;
                         const uint4 cc = kid_load_cell(db.table, ix);
                         atomicAdd(&WC[3], 1u);
-                        if (cc.z != 0 && cc.x == (uint32_t)g.key[u] && cc.y == (uint32_t)(g.key[u] >> 32)) { tgt[u] = cc.z; slot[u] = ix; go = false; }
+                        if (cc.z != 0 && cc.x == (uint32_t)g.key[u] && cc.y == (uint32_t)(g.key[u] >> 32)) { tgt[u] = cc.z; slot[u] = cc.w - 1u; go = false; }
                     } else if (fu) {
                         ln = (ln + 1u) & rare->line_mask;
                         const uint4 h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
@@ -641,7 +659,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                         if (step[u] > 1) atomicAdd(&WC[3], 1u);
                         if (c[u].z == 0) g.act[u] = false;
                         else if (c[u].x == (uint32_t)g.key[u] && c[u].y == (uint32_t)(g.key[u] >> 32)) {
-                            tgt[u] = c[u].z; slot[u] = idx[u]; g.act[u] = false;
+                            tgt[u] = c[u].z; slot[u] = c[u].w - 1u; g.act[u] = false;
                         } else if (!(rp[u] < db.nslots) || (db.max_probes != 0 && step[u] >= db.max_probes)) g.act[u] = false;
                     }
                     any |= g.act[u];
@@ -795,7 +813,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                 const uint32_t idx = ln * KID_LINE_CELLS + 1u + kid_cand_entry((uint32_t)__builtin_ctz(mu));
                 mu &= mu - 1;
                 const uint4 c = kid_load_cell(db.table, idx);
-                if (c.z != 0 && c.x == klo && c.y == khi) { tgt = c.z; slot = idx; }
+                if (c.z != 0 && c.x == klo && c.y == khi) { tgt = c.z; slot = c.w - 1u; }
             }
             bool go = valid && tgt == 0 && (mu != 0 || fu);
             while (go) { // a second candidate (1e-4 of the lookups) or a chained line (1e-5)
@@ -805,7 +823,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                     const uint32_t ix = ln * KID_LINE_CELLS + 1u + j;
                     const uint4 cc = kid_load_cell(db.table, ix);
                     atomicAdd(&WC[3], 1u);
-                    if (cc.z != 0 && cc.x == klo && cc.y == khi) { tgt = cc.z; slot = ix; go = false; }
+                    if (cc.z != 0 && cc.x == klo && cc.y == khi) { tgt = cc.z; slot = cc.w - 1u; go = false; }
                 } else if (fu) {
                     ln = (ln + 1u) & rare->line_mask;
                     const uint4 h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
@@ -1323,6 +1341,13 @@ __global__ void kid_lookup_kernel(const KidDevDb db, const uint64_t *keys, uint6
     }
 }
 
+// Hashtable::integerHash (newkmer_10nx.cpp:189-197) as the device computes it
+__global__ void kid_fmix_kernel(const uint64_t *keys, uint64_t n, uint64_t *out)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = kid_fmix64(keys[i]);
+}
+
 __global__ void kid_msca_kernel(const KidDevDb db, const int32_t *x, const int32_t *y, uint64_t n, int32_t *out)
 {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -1436,11 +1461,14 @@ __global__ void kid_build_insert_kernel(uint4 *table, uint32_t slot_mask, const 
 
 // Pass 2: the reference's lookup returns the FIRST-inserted copy of a key (earlier inserts sit
 // earlier on the path).  Pass 1 placed duplicate copies in arbitrary order, so every entry walks
-// its whole chain, finds the smallest ordinal among the cells holding its key and writes that
-// entry's target into ITS OWN cell: afterwards every copy carries the first insert's target and it
-// does not matter which copy a lookup meets first (it always meets the same one, so the seen-bit
-// of a key is unique too).  Keys, ordinals and headers are immutable here; each thread writes only
-// the target word of its own cell.
+// its whole chain, finds the smallest ordinal among the cells holding its key and, unless that is
+// its own, turns ITS OWN cell into a tombstone (a key no lookup can ask for: keys are below 2^62).
+// Afterwards the first insert is the only copy a lookup can match, wherever it sits -- and the
+// ordinal it carries (cell word 3) names the key independently of the placement, which is what
+// the per-sample seen-bitmap is indexed by.  A tombstone keeps its cell occupied and its
+// fingerprint in the header, like the reference's unreachable duplicates keep theirs.  The first
+// insert is never touched, so concurrent walkers always see it; each thread writes one word of
+// its own cell only.
 __global__ void kid_build_firstwins_kernel(uint4 *table, uint32_t slot_mask, const uint64_t *keys, const uint32_t *targets,
                                            uint64_t n, int k, uint32_t minloc, uint32_t line_shift, uint32_t line_mask)
 {
@@ -1483,15 +1511,16 @@ __global__ void kid_build_firstwins_kernel(uint4 *table, uint32_t slot_mask, con
                 }
             }
         }
-        if (copies > 1 && min_ord != (uint32_t)e + 1u) reinterpret_cast<uint32_t *>(table + my_idx)[2] = targets[min_ord - 1];
+        if (copies > 1 && min_ord != (uint32_t)e + 1u) reinterpret_cast<uint32_t *>(table + my_idx)[1] = KID_TOMBSTONE_HI;
     }
 }
 
 // ------------------------------------------------------------------ ucount from the seen-bitmap
 // ucount[t] = number of distinct DB k-mers of target t seen in the sample
-// (newkmer_10nx.cpp:596-603), counted over the cells [w_begin*32, w_end*32)
+// (newkmer_10nx.cpp:596-603), counted over the entry ordinals [w_begin*32, w_end*32): bit o of the
+// bitmap = "the key first inserted as entry o was hit", ord_target[o] = that entry's target
 template <bool HIST>
-__global__ void kid_ucount_kernel(const uint32_t *seen, uint64_t w_begin, uint64_t w_end, const uint4 *table,
+__global__ void kid_ucount_kernel(const uint32_t *seen, uint64_t w_begin, uint64_t w_end, const uint32_t *ord_target,
                                   unsigned long long *ucount, uint32_t ntar)
 {
     // the bitmap is almost empty: stream it 16 bytes per lane and only look inside non-zero words;
@@ -1513,7 +1542,7 @@ __global__ void kid_ucount_kernel(const uint32_t *seen, uint64_t w_begin, uint64
             while (bits) {
                 const uint32_t bpos = (uint32_t)__builtin_ctz(bits);
                 bits &= bits - 1;
-                const uint32_t t = table[(q * 4ull + (uint64_t)i) * 32ull + bpos].z;
+                const uint32_t t = ord_target[(q * 4ull + (uint64_t)i) * 32ull + bpos];
                 if (HIST) atomicAdd(&kid_uhist[t], 1u);
                 else atomicAdd(&ucount[t], 1ull);
             }

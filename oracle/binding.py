@@ -39,6 +39,7 @@ def load():
         "ko_db_get": (C.c_uint32, [vp, u64, vp]),
         "ko_classify_batch_timed": (C.c_double, [vp, vp, vp, vp, vp, u64]),
         "ko_db_get_batch": (None, [vp, vp, u64, vp, vp]),
+        "ko_classify_batch_mt": (C.c_double, [vp, vp, vp, vp, vp, u64, i32, vp, vp, vp]),
         "ko_db_process_kmer": (i32, [vp, C.c_char_p, C.c_size_t, C.c_uint32]),
         "ko_db_probe_line": (i32, [vp, C.c_char_p, C.c_size_t]),
         "ko_db_load_probes_gz": (C.c_longlong, [vp, C.c_char_p]),
@@ -98,6 +99,23 @@ class OracleDB:
 
     def msca(self, x, y):
         return self.lib.ko_msca(self.h, int(x), int(y))
+
+    def classify_mt(self, bases, offsets, threads):
+        """whole reads on `threads` host threads (shared table, per-thread counters, merged)
+        -> (seconds, gcount, ucount, stats)"""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        n = offsets.size - 1
+        lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+        start = np.zeros(n, np.int32)
+        stop = (lens - 1).astype(np.int32)
+        g = np.zeros(self.ntar, np.int64)
+        u = np.zeros(self.ntar, np.int64)
+        st = np.zeros(3, np.uint64)
+        sec = self.lib.ko_classify_batch_mt(self.h, _p(bases), _p(offsets), _p(start), _p(stop), n, int(threads), _p(g), _p(u), _p(st))
+        if sec < 0:
+            raise MemoryError("ko_classify_batch_mt failed")
+        return sec, g, u, {"lookups": int(st[0]), "probes": int(st[1]), "hits": int(st[2])}
 
     def load_probes_gz(self, path):
         return self.lib.ko_db_load_probes_gz(self.h, path.encode())

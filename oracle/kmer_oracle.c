@@ -486,6 +486,81 @@ double ko_classify_batch_timed(ko_sample *s, const uint8_t *bases, const uint64_
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
+/* ---- the same loop on several host threads (bench.py's all-cores cpu_baseline leg) ----
+ * The reference is single-threaded; this is what "the reference's CPU path on all host cores" can
+ * mean without changing its results: reads are independent given the table, so thread t runs
+ * ko_process_read over a contiguous range of the reads into counters of its own (the table and the
+ * tree are shared read-only; msca's scratch array is per thread), and the counters are merged the
+ * way the reference's globals would have ended up: gcount adds, kmer_seen is the union of the
+ * threads' sets, ucount counts the union once per key.  Returns wall seconds, merge included. */
+#include <pthread.h>
+typedef struct ko_mt_arg {
+    ko_db dbc; /* shallow copy: own msca scratch */
+    ko_sample *s;
+    const uint8_t *bases;
+    const uint64_t *offsets;
+    const int32_t *start, *stop;
+    uint64_t r0, r1;
+} ko_mt_arg;
+
+static void *ko_mt_worker(void *p)
+{
+    ko_mt_arg *a = (ko_mt_arg *)p;
+    for (uint64_t r = a->r0; r < a->r1; r++)
+        ko_process_read(a->s, (const char *)a->bases + a->offsets[r], a->start[r], a->stop[r], NULL);
+    return NULL;
+}
+
+double ko_classify_batch_mt(ko_db *db, const uint8_t *bases, const uint64_t *offsets, const int32_t *start,
+                            const int32_t *stop, uint64_t n, int nthreads, int64_t *gcount_out, int64_t *ucount_out,
+                            uint64_t *stats3)
+{
+    if (nthreads < 1) nthreads = 1;
+    if ((uint64_t)nthreads > n && n > 0) nthreads = (int)n;
+    ko_mt_arg *args = (ko_mt_arg *)calloc((size_t)nthreads, sizeof(ko_mt_arg));
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    if (!args || !th) { free(args); free(th); return -1.0; }
+    for (int t = 0; t < nthreads; t++) {
+        args[t].dbc = *db;
+        args[t].dbc.mark = (uint32_t *)calloc((size_t)db->ntar, sizeof(uint32_t));
+        args[t].dbc.mark_gen = 0;
+        args[t].s = ko_sample_new(&args[t].dbc);
+        if (!args[t].dbc.mark || !args[t].s) {
+            for (int u = 0; u <= t; u++) { ko_sample_free(args[u].s); free(args[u].dbc.mark); }
+            free(args); free(th);
+            return -1.0;
+        }
+        args[t].bases = bases; args[t].offsets = offsets; args[t].start = start; args[t].stop = stop;
+        args[t].r0 = n * (uint64_t)t / (uint64_t)nthreads;
+        args[t].r1 = n * (uint64_t)(t + 1) / (uint64_t)nthreads;
+    }
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 1; t < nthreads; t++) pthread_create(&th[t], NULL, ko_mt_worker, &args[t]);
+    ko_mt_worker(&args[0]);
+    for (int t = 1; t < nthreads; t++) pthread_join(th[t], NULL);
+    ko_sample *m = args[0].s;
+    for (int t = 1; t < nthreads; t++) {
+        const ko_sample *o = args[t].s;
+        for (int i = 0; i < db->ntar; i++) m->gcount[i] += o->gcount[i];
+        m->tct += o->tct;
+        m->n_lookups += o->n_lookups; m->n_probes += o->n_probes; m->n_hits += o->n_hits;
+        for (uint64_t i = 0; i < o->seen_cap; i++) {
+            const uint64_t key = o->seen[i];
+            if (key == ~0ULL || !ko_seen_add(m, key)) continue;
+            uint32_t probes;
+            m->ucount[ko_db_get(db, key, &probes)]++; /* the target the key was credited to (:600) */
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    memcpy(gcount_out, m->gcount, sizeof(int64_t) * (size_t)db->ntar);
+    memcpy(ucount_out, m->ucount, sizeof(int64_t) * (size_t)db->ntar);
+    if (stats3) { stats3[0] = m->n_lookups; stats3[1] = m->n_probes; stats3[2] = m->n_hits; }
+    for (int t = 0; t < nthreads; t++) { ko_sample_free(args[t].s); free(args[t].dbc.mark); }
+    free(args); free(th);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
 /* ---- process_qual, newkmer_10nx.cpp:714-760 ----
  * qual bytes are compared as (signed) char exactly like std::string::at()
  * returns on x86.  Returns 1 if process_read would be called (stop-start >= k),

@@ -500,6 +500,51 @@ def test_seen_bitmap_export_or_and_ranges(seeded):
         s_.close()
 
 
+def test_fmix64_golden_on_gpu(kat):
+    """Hashtable::integerHash as the device computes it, against the reference's own values"""
+    assert np.array_equal(kmer_id_amd.hash_keys(kat["fmix_in"]), kat["fmix_out"])
+
+
+@pytest.mark.parametrize("flags_b", [0, KID_FLAG_REF_GEOMETRY, KID_FLAG_HOST_BUILD])
+def test_seen_bitmaps_merge_across_independent_tables(flags_b):
+    """What N ranks do: every rank builds ITS OWN replica of the table (cell placement depends on the race order of
+    the GPU builder, or is another geometry altogether), classifies its shard and ORs seen-bitmaps with the others.
+    Bits are entry ordinals, so the merge must be exact whatever the placements -- duplicates included: the DB holds
+    keys inserted twice with different targets (first insert wins) and a target-0 entry."""
+    parent, cum, keys, targets = small_db(1e-3)
+    rng = np.random.default_rng(5)
+    dup = rng.choice(keys.size, 3000, replace=False)
+    keys = np.concatenate([keys, keys[dup], keys[dup[:500]]])
+    targets = np.concatenate([targets, (targets[dup] % 5000 + 7).astype(np.uint32), np.full(500, 2, np.uint32)])
+    targets[dup[:20]] = 0  # first insert leaves the cell empty: the later copy with a target becomes visible
+    odb = oracle_db(parent, keys, targets, 20)
+    db_a = KmerDB(keys, targets, parent, k=K, log2_slots=20)
+    db_b = KmerDB(keys, targets, parent, k=K, log2_slots=20, flags=flags_b)
+    n, L = 16000, 150
+    bases = synth.reads(cum, parent, n, L, K, r0=777)
+    # make sure the duplicated keys are hit: implant some of them
+    for j, e in enumerate(dup[:2000].tolist()):
+        v = int(keys[e])
+        bases[j * L + 40:j * L + 70] = np.frombuffer(bytes("ACGT"[(v >> (2 * (29 - i))) & 3] for i in range(30)).encode(), np.uint8)
+    off = synth.fixed_offsets(n, L)
+    os_ = ob.OracleSample(odb)
+    exp = os_.classify(bases, off)
+    eg, eu = os_.counts()
+    a = db_a.sample(); fa = a.classify(bases, off[:n // 2 + 1])
+    b = db_b.sample(); fb = b.classify(bases, off[n // 2:])
+    assert np.array_equal(np.concatenate([fa, fb]), exp)
+    nbytes = a.seen_bytes()
+    assert nbytes == b.seen_bytes()
+    half = (nbytes // 2) & ~15
+    a.seen_or(0, b.seen_export(0, half))
+    b.seen_or(half, a.seen_export(half, nbytes - half))
+    u = a.ucount_range(0, half * 8) + b.ucount_range(half * 8, nbytes * 8)
+    assert np.array_equal(a.gcount() + b.gcount(), eg)
+    assert np.array_equal(u, eu)
+    for x in (a, b, db_a, db_b):
+        x.close()
+
+
 def test_merge_sample_over_rccl_single_rank(seeded):
     """kmer_id_amd.dist.merge_sample with the collectives forced on (world size 1, backend nccl = RCCL)"""
     import os
