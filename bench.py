@@ -125,6 +125,95 @@ def cpu_baseline(host_keys, parent, cum, log2_slots, n_reads, threads):
                                               threads, sec_mt, st_mt["lookups"] / sec_mt / 1e6, build_s)}, (g, u)
 
 
+def host_buffer_leg(db, device, batches, n_reads, steps):
+    """The same batches handed over as HOST buffers (pinned, kid_host_alloc) through kid_classify_fixed_async: upload on
+    a copy stream, kernels, per-read results back on a result stream, three batches in flight.  PCIe-inclusive
+    pairs/s: never the headline value (the metric is quoted with reads resident in HBM)."""
+    from kmer_id_amd import PinnedBuffer
+    import ctypes as C
+    lib = kmer_id_amd.load()
+    nb = min(len(batches), 3)
+    nbytes = n_reads * READ_LEN
+    pins = [PinnedBuffer(nbytes) for _ in range(nb)]
+    outs = [PinnedBuffer(n_reads * 4) for _ in range(3)]
+    for b_, pin in zip(batches, pins):
+        kmer_id_amd._lib.check(lib.kid_dev_download(device.index, C.c_void_p(pin.ptr), C.c_void_p(b_.data_ptr()), nbytes))
+    s_ = db.sample()
+
+    def run(k):
+        tickets = []
+        for i in range(k):
+            tickets.append(s_.classify_fixed_async(pins[i % nb].ptr, READ_LEN, n_reads, outs[i % 3].ptr))
+            if len(tickets) > 2:
+                s_.wait(tickets.pop(0))
+        for t_ in tickets:
+            s_.wait(t_)
+    run(3)
+    s_.reset()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    run(steps)
+    g, u = s_.end()
+    sec = time.perf_counter() - t0
+    ok = int(g.sum()) == steps * n_reads
+    s_.close()
+    for p_ in pins + outs:
+        p_.close()
+    return {"pairs_per_s": steps * (n_reads // 2) / sec, "steps": steps, "GBps_h2d": steps * nbytes / sec / 1e9,
+            "counts_add_up": ok,
+            "what": "kid_classify_fixed_async from pinned host memory, 3 batches in flight, per-read results copied back; "
+                    "sample closed (ucount) inside the timed region"}
+
+
+def cli_e2e_leg(threads):
+    """nk10 (the reference's command line) on a directory of FASTQ.gz pairs: files in -> _result.txt/_reads.txt out.
+    Host-bound (gzip inflate + parsing); a small DB scale so that the text DB load is not what is measured."""
+    import subprocess
+    import tempfile
+    from kmer_id_amd import _build
+    nk10 = _build.cli_path("nk10")
+    if not os.path.exists(nk10):
+        return None
+    S, P = 2, 100_000
+    cwd = tempfile.mkdtemp(prefix="kid_e2e_")
+    try:
+        parent, cnt = synth.load_taxonomy("bact10")
+        cum = synth.cumulative(synth.scaled_counts(cnt, 1e-3))
+        keys, targets = synth.db_keys(cum, K)
+        os.makedirs(os.path.join(cwd, "bact10"))
+        with open(os.path.join(cwd, "bact10", "btree_10.txt"), "w") as fh:
+            for y, x in enumerate(parent.tolist()):
+                if y >= 2 and x != 1:
+                    fh.write("%d\t%d\n" % (x, y))
+        open(os.path.join(cwd, "bact10", "bData10.txt"), "w").write("4\tX\n")
+        synth.write_probes_gz(os.path.join(cwd, "bact10", "probes10.txt.gz"), keys, targets, K)
+        fq, empty = os.path.join(cwd, "fq") + "/", os.path.join(cwd, "empty") + "/"
+        os.makedirs(fq); os.makedirs(empty)
+        for s_ in range(S):
+            for mate in (1, 2):
+                r0 = (2 * s_ + mate - 1) * P
+                synth.write_fastq_gz(fq + "S%d_R%d_tr.fastq.gz" % (s_, mate), synth.reads(cum, parent, P, 150, K, r0=r0),
+                                     synth.qualities(P, 150, r0=r0), 150, mate=mate)
+        cache = os.path.join(cwd, "db.kidx")
+
+        def run(d):
+            t = time.perf_counter()
+            subprocess.run([nk10, d, "--log2-slots", "22", "--db-cache", cache, "--threads", str(threads)], cwd=cwd, check=True,
+                           stdout=subprocess.DEVNULL)
+            return time.perf_counter() - t
+        run(empty)
+        base = min(run(empty) for _ in range(2))
+        wall = run(fq)
+        g = sum(int(line.split(",")[1]) for line in open(fq + "S0_result.txt"))
+        return {"pairs_per_s": S * P / max(wall - base, 1e-6), "wall_s": wall, "startup_s": base, "samples": S, "pairs_per_sample": P,
+                "reader_threads": threads, "reads_counted_sample0": g,
+                "what": "nk10 <dir> on %d samples x %d pairs of 150 bp FASTQ.gz (mixed qualities, trimmed by process_qual), wall minus "
+                        "the program's startup on an empty directory; bounded by gzip inflate + parsing on the host" % (S, P)}
+    finally:
+        import shutil
+        shutil.rmtree(cwd, ignore_errors=True)
+
+
 PMC_PROFILES = {"1m": ["profiles/r02/pmc_final.json", "profiles/r01/pmc_final.json"],
                 "roofline100m": ["profiles/r02/pmc_100m.json"]}
 
@@ -164,6 +253,8 @@ def main():
     ap.add_argument("--cpu-reads", type=int, default=300_000, help="reads of the CPU baseline sample (0 = skip)")
     ap.add_argument("--batches", type=int, default=None, help="distinct resident read batches cycled over the steps")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline leg (0 = every core of this host)")
+    ap.add_argument("--host-leg", type=int, default=1, help="N = 1: also time the host-buffer (PCIe-inclusive) path")
+    ap.add_argument("--e2e-leg", type=int, default=1, help="N = 1: also time the nk10 command line on FASTQ.gz files")
     ap.add_argument("--verify-ranks", type=int, default=1,
                     help="N > 1: rank 0 re-classifies every rank's reads on its own table after the timed region and compares "
                          "the merged counters with that single-table result")
@@ -306,6 +397,18 @@ def main():
             extra["gather16B_%d_inflight_GBps" % inflight] = round(loads * 16 / (ms / 1e3) / 1e9, 1)
             extra["gather16B_%d_inflight_Gloads_per_s" % inflight] = round(loads / (ms / 1e3) / 1e9, 2)
 
+    host_leg = e2e_leg = None
+    if rank == 0 and world == 1 and args.config == "1m":
+        if args.host_leg:
+            log("host-buffer leg ...")
+            host_leg = host_buffer_leg(db, device, batches, n_reads, max(4, min(args.steps, 12)))
+        if args.e2e_leg:
+            log("nk10 FASTQ.gz leg ...")
+            try:
+                e2e_leg = cli_e2e_leg(min(8, host_cores()))
+            except Exception as e:  # the CLI leg must not take the metric down with it
+                e2e_leg = {"error": repr(e)}
+
     cpu = None
     if want_cpu:
         threads = args.cpu_threads or host_cores()
@@ -375,6 +478,8 @@ def main():
                          "lookups_per_s": st["lookups"] / (classify_ms / 1e3), "kernel_only_pairs_per_s": args.pairs / avg_kernel_s,
                          **extra},
             "cpu_baseline": cpu,
+            "host_buffer_path": host_leg,
+            "cli_fastq_gz": e2e_leg,
         }
         print(json.dumps(line), flush=True)
     sample.close()

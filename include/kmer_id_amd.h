@@ -125,8 +125,26 @@ void kid_sample_destroy(kid_sample *s);
 int kid_classify_batch(kid_sample *s, const uint8_t *bases, const uint64_t *offsets,
                        const int32_t *start, const int32_t *stop, uint64_t n_reads,
                        uint32_t *out_final_targ);
+/* The same, asynchronous: returns once the batch has been queued -- its upload (a copy stream), its kernels (the
+ * sample's stream) and the download of out_final_targ (a result stream) overlap with those of the batches before and
+ * after it; up to three batches are in flight, a fourth call waits for the oldest.  The caller's buffers (inputs AND
+ * out_final_targ) belong to the library until kid_classify_wait(ticket) returns.  Buffers from kid_host_alloc (pinned)
+ * are transferred by DMA straight from / to the caller's memory; pageable ones work too but are staged by the HIP
+ * runtime.  This replaces the reader loop of process_fqgz (newkmer_10nx.cpp:762-816) handing reads to process_read one
+ * at a time.  kid_sample_end waits for everything in flight.                                                     */
+int kid_classify_batch_async(kid_sample *s, const uint8_t *bases, const uint64_t *offsets,
+                             const int32_t *start, const int32_t *stop, uint64_t n_reads,
+                             uint32_t *out_final_targ, uint64_t *ticket);
+/* fixed-length whole reads laid out back to back in host memory (no offsets array to upload) */
+int kid_classify_fixed_async(kid_sample *s, const uint8_t *bases, uint32_t read_len, uint64_t n_reads,
+                             uint32_t *out_final_targ, uint64_t *ticket);
+int kid_classify_wait(kid_sample *s, uint64_t ticket);
+/* pinned (page-locked) host memory for the buffers above */
+int kid_host_alloc(uint64_t nbytes, void **ptr);
+int kid_host_free(void *ptr);
 /* Device-resident form, asynchronous on `stream` (a hipStream_t, NULL = default
- * stream).  bases_nbytes = offsets[n_reads] (size of the read text); d_bases must be
+ * stream).  A sample has ONE set of scratch buffers: batches handed over on different
+ * streams are ordered behind each other by the library (an event wait), they do not overlap.  bases_nbytes = offsets[n_reads] (size of the read text); d_bases must be
  * 16-byte aligned and its allocation must extend at least 16 bytes past bases_nbytes
  * (the pack kernel reads aligned 16-byte chunks).                                 */
 int kid_classify_batch_device(kid_sample *s, const void *d_bases, uint64_t bases_nbytes,

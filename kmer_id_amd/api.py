@@ -31,6 +31,30 @@ def hash_keys(keys, device=0):
     return out
 
 
+class PinnedBuffer:
+    """Page-locked host memory from the library (kid_host_alloc), viewed as a numpy array."""
+
+    def __init__(self, nbytes):
+        self._lib = _lib.load()
+        p = C.c_void_p()
+        check(self._lib.kid_host_alloc(nbytes, C.byref(p)))
+        self.ptr = p.value
+        self.nbytes = nbytes
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (nbytes,))
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self._lib.kid_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class KmerDB:
     """Replaces `new Hashtable()` + `new Tree1()` + the add_kmer/add_edge load loops."""
 
@@ -139,6 +163,23 @@ class Sample:
         out = np.empty(n, np.uint32) if want_final else None
         check(self._lib.kid_classify_batch(self._h, _ptr(bases), _ptr(offsets), _ptr(start), _ptr(stop), n, _ptr(out)))
         return out
+
+    def classify_async(self, bases, offsets, start=None, stop=None, out=None):
+        """Queue a batch held in host memory (numpy arrays or PinnedBuffer views, which the caller keeps alive and
+        untouched until wait(ticket)); -> ticket.  `out`: uint32[n] array that receives final_targ."""
+        n = offsets.size - 1
+        t = C.c_uint64(0)
+        check(self._lib.kid_classify_batch_async(self._h, _ptr(bases), _ptr(offsets), _ptr(start), _ptr(stop), n, _ptr(out), C.byref(t)))
+        return t.value
+
+    def classify_fixed_async(self, bases_ptr, read_len, n_reads, out_ptr=0):
+        """fixed-length whole reads back to back at the raw host address bases_ptr; -> ticket"""
+        t = C.c_uint64(0)
+        check(self._lib.kid_classify_fixed_async(self._h, C.c_void_p(bases_ptr), read_len, n_reads, C.c_void_p(out_ptr or None), C.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        check(self._lib.kid_classify_wait(self._h, ticket))
 
     def classify_device(self, d_bases, bases_nbytes, d_offsets, n_reads, d_start=0, d_stop=0, d_out=0, stream=0):
         """Asynchronous, device-resident inputs (raw pointers)."""

@@ -92,13 +92,24 @@ struct kid_sample {
     uint32_t *sc_codes = nullptr;
     uint16_t *sc_inval = nullptr;
     uint64_t sc_chunks_cap = 0;
-    // staging for the host-buffer entry point
-    uint8_t *st_bases = nullptr;
-    uint64_t st_bases_cap = 0;
-    uint64_t *st_offsets = nullptr;
-    int32_t *st_start = nullptr, *st_stop = nullptr;
-    uint32_t *st_out = nullptr;
-    uint64_t st_reads_cap = 0;
+    // Staging for the host-buffer entry points: a ring of slots so that the upload of batch b + 1 (copy stream) and
+    // the download of batch b - 1's results (result stream) run beside the kernels of batch b (the sample's stream).
+    struct Slot {
+        uint8_t *bases = nullptr;
+        uint64_t bases_cap = 0;
+        uint64_t *offsets = nullptr;
+        int32_t *start = nullptr, *stop = nullptr;
+        uint32_t *out = nullptr;
+        uint64_t reads_cap = 0;
+        hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_out = nullptr;
+        std::vector<uint64_t> rel; // offsets rebased to the slot (alive until the copy has been issued AND done)
+        uint64_t ticket = 0;
+        bool busy = false;
+    };
+    static const int NSLOT = 3;
+    Slot slots[NSLOT];
+    hipStream_t copy_stream = nullptr, out_stream = nullptr;
+    uint64_t next_ticket = 1;
 };
 
 extern "C" const char *kid_strerror(int status)
@@ -491,11 +502,19 @@ extern "C" void kid_sample_destroy(kid_sample *s)
     if (s->sc_desc) hipFree(s->sc_desc);
     if (s->sc_codes) hipFree(s->sc_codes);
     if (s->sc_inval) hipFree(s->sc_inval);
-    if (s->st_bases) hipFree(s->st_bases);
-    if (s->st_offsets) hipFree(s->st_offsets);
-    if (s->st_start) hipFree(s->st_start);
-    if (s->st_stop) hipFree(s->st_stop);
-    if (s->st_out) hipFree(s->st_out);
+    hipDeviceSynchronize();
+    for (kid_sample::Slot &sl : s->slots) {
+        if (sl.bases) hipFree(sl.bases);
+        if (sl.offsets) hipFree(sl.offsets);
+        if (sl.start) hipFree(sl.start);
+        if (sl.stop) hipFree(sl.stop);
+        if (sl.out) hipFree(sl.out);
+        if (sl.ev_h2d) hipEventDestroy(sl.ev_h2d);
+        if (sl.ev_done) hipEventDestroy(sl.ev_done);
+        if (sl.ev_out) hipEventDestroy(sl.ev_out);
+    }
+    if (s->copy_stream) hipStreamDestroy(s->copy_stream);
+    if (s->out_stream) hipStreamDestroy(s->out_stream);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
 }
@@ -762,10 +781,75 @@ extern "C" int kid_classify_fixed_device(kid_sample *s, const void *d_bases, uin
     return kid_launch_classify(s, b, n_reads * (uint64_t)read_len, (hipStream_t)stream, nk > 0 ? nk : 0);
 }
 
-extern "C" int kid_classify_batch(kid_sample *s, const uint8_t *bases, const uint64_t *offsets, const int32_t *start,
-                                  const int32_t *stop, uint64_t n_reads, uint32_t *out_final_targ)
+// ---- host buffers: asynchronous slot pipeline -------------------------------------------------------------------
+static int kid_slot_acquire(kid_sample *s, uint64_t n_reads, uint64_t nbytes, bool with_offsets, bool with_range,
+                            kid_sample::Slot **out)
+{
+    if (!s->copy_stream) KID_HIP(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+    if (!s->out_stream) KID_HIP(hipStreamCreateWithFlags(&s->out_stream, hipStreamNonBlocking));
+    kid_sample::Slot &sl = s->slots[s->next_ticket % kid_sample::NSLOT];
+    if (!sl.ev_h2d) {
+        KID_HIP(hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
+        KID_HIP(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+        KID_HIP(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
+    }
+    if (sl.busy) { // the batch that used this slot three tickets ago
+        KID_HIP(hipEventSynchronize(sl.ev_out));
+        sl.busy = false;
+    }
+    const uint64_t need = ((nbytes + 15) & ~15ull) + 32;
+    if (need > sl.bases_cap) {
+        if (sl.bases) KID_HIP(hipFree(sl.bases));
+        sl.bases = nullptr; sl.bases_cap = 0;
+        const uint64_t cap = need + need / 8; // a little slack: batches of a file differ slightly in size
+        KID_HIP(hipMalloc(&sl.bases, cap));
+        sl.bases_cap = cap;
+    }
+    if (n_reads > sl.reads_cap) {
+        if (sl.offsets) KID_HIP(hipFree(sl.offsets));
+        if (sl.start) KID_HIP(hipFree(sl.start));
+        if (sl.stop) KID_HIP(hipFree(sl.stop));
+        if (sl.out) KID_HIP(hipFree(sl.out));
+        sl.offsets = nullptr; sl.start = sl.stop = nullptr; sl.out = nullptr; sl.reads_cap = 0;
+        const uint64_t cap = n_reads + n_reads / 8;
+        KID_HIP(hipMalloc(&sl.offsets, (cap + 1) * 8));
+        KID_HIP(hipMalloc(&sl.start, cap * 4));
+        KID_HIP(hipMalloc(&sl.stop, cap * 4));
+        KID_HIP(hipMalloc(&sl.out, cap * 4));
+        sl.reads_cap = cap;
+    }
+    (void)with_offsets; (void)with_range;
+    *out = &sl;
+    return KID_OK;
+}
+
+// upload issued on the copy stream -> kernels on the sample's stream -> results on the result stream
+static int kid_slot_submit(kid_sample *s, kid_sample::Slot &sl, const KidBatch &b, uint64_t nbytes, int64_t max_kmers,
+                           uint32_t *out_final_targ, uint64_t *ticket)
+{
+    KID_HIP(hipEventRecord(sl.ev_h2d, s->copy_stream));
+    KID_HIP(hipStreamWaitEvent(s->stream, sl.ev_h2d, 0));
+    int rc = kid_launch_classify(s, b, nbytes, s->stream, max_kmers);
+    if (rc != KID_OK) return rc;
+    KID_HIP(hipEventRecord(sl.ev_done, s->stream));
+    if (out_final_targ) {
+        KID_HIP(hipStreamWaitEvent(s->out_stream, sl.ev_done, 0));
+        KID_HIP(hipMemcpyAsync(out_final_targ, sl.out, b.n * 4, hipMemcpyDeviceToHost, s->out_stream));
+        KID_HIP(hipEventRecord(sl.ev_out, s->out_stream));
+    } else {
+        KID_HIP(hipEventRecord(sl.ev_out, s->stream));
+    }
+    sl.busy = true;
+    sl.ticket = s->next_ticket++;
+    if (ticket) *ticket = sl.ticket;
+    return KID_OK;
+}
+
+extern "C" int kid_classify_batch_async(kid_sample *s, const uint8_t *bases, const uint64_t *offsets, const int32_t *start,
+                                        const int32_t *stop, uint64_t n_reads, uint32_t *out_final_targ, uint64_t *ticket)
 {
     if (!s) return kid_fail(KID_ERR_ARG, "null sample");
+    if (ticket) *ticket = 0;
     if (n_reads == 0) return KID_OK;
     if (!bases || !offsets) return kid_fail(KID_ERR_ARG, "null argument");
     if ((start == nullptr) != (stop == nullptr)) return kid_fail(KID_ERR_ARG, "start and stop must both be given or both be null");
@@ -783,51 +867,98 @@ extern "C" int kid_classify_batch(kid_sample *s, const uint8_t *bases, const uin
     int rc = kid_use_device(s->db->device);
     if (rc != KID_OK) return rc;
     const uint64_t base0 = offsets[0], nbytes = offsets[n_reads] - base0;
-    const uint64_t need = ((nbytes + 15) & ~15ull) + 32;
-    if (need > s->st_bases_cap) {
-        if (s->st_bases) hipFree(s->st_bases);
-        s->st_bases = nullptr; s->st_bases_cap = 0;
-        KID_HIP(hipMalloc(&s->st_bases, need));
-        s->st_bases_cap = need;
-    }
-    if (n_reads > s->st_reads_cap) {
-        if (s->st_offsets) hipFree(s->st_offsets);
-        if (s->st_start) hipFree(s->st_start);
-        if (s->st_stop) hipFree(s->st_stop);
-        if (s->st_out) hipFree(s->st_out);
-        s->st_offsets = nullptr; s->st_start = s->st_stop = nullptr; s->st_out = nullptr; s->st_reads_cap = 0;
-        KID_HIP(hipMalloc(&s->st_offsets, (n_reads + 1) * 8));
-        KID_HIP(hipMalloc(&s->st_start, n_reads * 4));
-        KID_HIP(hipMalloc(&s->st_stop, n_reads * 4));
-        KID_HIP(hipMalloc(&s->st_out, n_reads * 4));
-        s->st_reads_cap = n_reads;
-    }
-    hipStream_t st = s->stream;
-    std::vector<uint64_t> rel;
+    kid_sample::Slot *slp = nullptr;
+    rc = kid_slot_acquire(s, n_reads, nbytes, true, start != nullptr, &slp);
+    if (rc != KID_OK) return rc;
+    kid_sample::Slot &sl = *slp;
+    hipStream_t cs = s->copy_stream;
     const uint64_t *off_src = offsets;
     if (base0 != 0) {
-        rel.resize(n_reads + 1);
-        for (uint64_t r = 0; r <= n_reads; r++) rel[r] = offsets[r] - base0;
-        off_src = rel.data();
+        sl.rel.resize(n_reads + 1);
+        for (uint64_t r = 0; r <= n_reads; r++) sl.rel[r] = offsets[r] - base0;
+        off_src = sl.rel.data();
     }
-    KID_HIP(hipMemsetAsync(s->st_bases + (nbytes & ~15ull), 0, need - (nbytes & ~15ull), st));
-    if (nbytes) KID_HIP(hipMemcpyAsync(s->st_bases, bases + base0, nbytes, hipMemcpyHostToDevice, st));
-    KID_HIP(hipMemcpyAsync(s->st_offsets, off_src, (n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+    const uint64_t need = ((nbytes + 15) & ~15ull) + 32;
+    KID_HIP(hipMemsetAsync(sl.bases + (nbytes & ~15ull), 0, need - (nbytes & ~15ull), cs));
+    if (nbytes) KID_HIP(hipMemcpyAsync(sl.bases, bases + base0, nbytes, hipMemcpyHostToDevice, cs));
+    KID_HIP(hipMemcpyAsync(sl.offsets, off_src, (n_reads + 1) * 8, hipMemcpyHostToDevice, cs));
     if (start) {
-        KID_HIP(hipMemcpyAsync(s->st_start, start, n_reads * 4, hipMemcpyHostToDevice, st));
-        KID_HIP(hipMemcpyAsync(s->st_stop, stop, n_reads * 4, hipMemcpyHostToDevice, st));
+        KID_HIP(hipMemcpyAsync(sl.start, start, n_reads * 4, hipMemcpyHostToDevice, cs));
+        KID_HIP(hipMemcpyAsync(sl.stop, stop, n_reads * 4, hipMemcpyHostToDevice, cs));
     }
     KidBatch b{};
-    b.bases = s->st_bases;
-    b.offsets = s->st_offsets;
-    b.start = start ? s->st_start : nullptr;
-    b.stop = start ? s->st_stop : nullptr;
-    b.out_final = s->st_out;
+    b.bases = sl.bases;
+    b.offsets = sl.offsets;
+    b.start = start ? sl.start : nullptr;
+    b.stop = start ? sl.stop : nullptr;
+    b.out_final = sl.out;
     b.n = n_reads;
-    rc = kid_launch_classify(s, b, nbytes, st, max_kmers);
+    return kid_slot_submit(s, sl, b, nbytes, max_kmers, out_final_targ, ticket);
+}
+
+extern "C" int kid_classify_fixed_async(kid_sample *s, const uint8_t *bases, uint32_t read_len, uint64_t n_reads,
+                                        uint32_t *out_final_targ, uint64_t *ticket)
+{
+    if (!s) return kid_fail(KID_ERR_ARG, "null sample");
+    if (ticket) *ticket = 0;
+    if (n_reads == 0) return KID_OK;
+    if (!bases) return kid_fail(KID_ERR_ARG, "null argument");
+    if (read_len == 0 || read_len > 0x7FFFFFFFu) return kid_fail(KID_ERR_ARG, "read_len out of range");
+    int rc = kid_use_device(s->db->device);
     if (rc != KID_OK) return rc;
-    if (out_final_targ) KID_HIP(hipMemcpyAsync(out_final_targ, s->st_out, n_reads * 4, hipMemcpyDeviceToHost, st));
-    KID_HIP(hipStreamSynchronize(st));
+    const uint64_t nbytes = n_reads * (uint64_t)read_len;
+    kid_sample::Slot *slp = nullptr;
+    rc = kid_slot_acquire(s, n_reads, nbytes, false, false, &slp);
+    if (rc != KID_OK) return rc;
+    kid_sample::Slot &sl = *slp;
+    const uint64_t need = ((nbytes + 15) & ~15ull) + 32;
+    KID_HIP(hipMemsetAsync(sl.bases + (nbytes & ~15ull), 0, need - (nbytes & ~15ull), s->copy_stream));
+    KID_HIP(hipMemcpyAsync(sl.bases, bases, nbytes, hipMemcpyHostToDevice, s->copy_stream));
+    KidBatch b{};
+    b.bases = sl.bases;
+    b.out_final = sl.out;
+    b.n = n_reads;
+    b.fixed_len = read_len;
+    const int64_t nk = (int64_t)read_len - s->db->info.k + 1;
+    return kid_slot_submit(s, sl, b, nbytes, nk > 0 ? nk : 0, out_final_targ, ticket);
+}
+
+extern "C" int kid_classify_wait(kid_sample *s, uint64_t ticket)
+{
+    if (!s) return kid_fail(KID_ERR_ARG, "null sample");
+    if (ticket == 0) return KID_OK; // an empty batch
+    if (ticket >= s->next_ticket) return kid_fail(KID_ERR_ARG, "ticket %llu has not been issued", (unsigned long long)ticket);
+    kid_sample::Slot &sl = s->slots[ticket % kid_sample::NSLOT];
+    if (sl.ticket != ticket || !sl.busy) return KID_OK; // its slot has been waited for (and maybe reused) already
+    int rc = kid_use_device(s->db->device);
+    if (rc != KID_OK) return rc;
+    KID_HIP(hipEventSynchronize(sl.ev_out));
+    sl.busy = false;
+    return KID_OK;
+}
+
+extern "C" int kid_classify_batch(kid_sample *s, const uint8_t *bases, const uint64_t *offsets, const int32_t *start,
+                                  const int32_t *stop, uint64_t n_reads, uint32_t *out_final_targ)
+{
+    uint64_t ticket = 0;
+    int rc = kid_classify_batch_async(s, bases, offsets, start, stop, n_reads, out_final_targ, &ticket);
+    if (rc != KID_OK) return rc;
+    return kid_classify_wait(s, ticket);
+}
+
+extern "C" int kid_host_alloc(uint64_t nbytes, void **ptr)
+{
+    if (!ptr) return kid_fail(KID_ERR_ARG, "null argument");
+    *ptr = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return kid_fail(KID_ERR_NO_DEVICE, "no HIP device: no pinned host memory");
+    KID_HIP(hipHostMalloc(ptr, nbytes ? nbytes : 16, hipHostMallocDefault));
+    return KID_OK;
+}
+
+extern "C" int kid_host_free(void *ptr)
+{
+    if (ptr) KID_HIP(hipHostFree(ptr));
     return KID_OK;
 }
 

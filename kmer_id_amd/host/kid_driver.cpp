@@ -139,16 +139,35 @@ std::unique_ptr<ReadBatch> Prefetcher::next(size_t index)
 
 long long run_file(Engine &e, Prefetcher &pf, size_t index, ReadSaver &saver)
 {
+    // Two batches in flight (kid_classify_batch_async): while the GPU classifies batch b, batch b + 1 is uploaded and
+    // the results of batch b - 1 go through the read saver -- in file order, which is what decides the "first 12
+    // reads of a target" (newkmer_10nx.cpp:608-612).
+    struct InFlight {
+        std::unique_ptr<ReadBatch> batch;
+        std::vector<uint32_t> final_targ;
+        uint64_t ticket = 0;
+    };
+    std::deque<InFlight> q;
     long long n = 0;
-    std::vector<uint32_t> final_targ;
-    while (std::unique_ptr<ReadBatch> b = pf.next(index)) {
-        final_targ.resize(b->size());
-        int rc = kid_classify_batch(e.sample, b->bases.data(), b->offsets.data(), b->start.data(), b->stop.data(), b->size(),
-                                    final_targ.data());
+    auto retire = [&]() {
+        InFlight &f = q.front();
+        int rc = kid_classify_wait(e.sample, f.ticket);
         if (rc != KID_OK) die_kid(rc);
-        saver.add_batch(*b, final_targ);
-        n += (long long)b->size();
+        saver.add_batch(*f.batch, f.final_targ);
+        q.pop_front();
+    };
+    while (std::unique_ptr<ReadBatch> b = pf.next(index)) {
+        q.emplace_back();
+        InFlight &f = q.back();
+        f.batch = std::move(b);
+        f.final_targ.resize(f.batch->size());
+        int rc = kid_classify_batch_async(e.sample, f.batch->bases.data(), f.batch->offsets.data(), f.batch->start.data(),
+                                          f.batch->stop.data(), f.batch->size(), f.final_targ.data(), &f.ticket);
+        if (rc != KID_OK) die_kid(rc);
+        n += (long long)f.batch->size();
+        while (q.size() > 2) retire();
     }
+    while (!q.empty()) retire();
     return n;
 }
 

@@ -121,3 +121,47 @@ def test_full_size_sample_against_the_oracle(full):
     assert abs(s.stats()["probes"] - os_.stats()["probes"]) < 1e-3 * os_.stats()["probes"]
     s.close()
     odb.close()
+
+
+def test_config3_100m_pairs_properties(full):
+    """BASELINE config 3: 100 M pairs = 200 M reads of 150 bp resident in HBM (30 GB), one sample, ONE call -- which the
+    library classifies in several launches so that a workgroup's 16-bit LDS histogram cannot overflow.  No oracle can
+    follow at this size; what must hold: every read is counted once, the per-read results of a 2 M-read slice equal those
+    of the reference-geometry table, the counters equal those of the same reads handed over in two halves (gcount adds,
+    ucount through the OR of the seen-bitmaps), and the first 2 M reads are the reads of the other tests (same answers)."""
+    lib = kmer_id_amd.load()
+    db, rdb = full["db"], full["rdb"]
+    n = 200_000_000
+    reads = DevBuf(n * READ_LEN + 64)
+    cum, parent = full["cum"], full["parent"]
+    _lib.check(lib.kid_synth_reads_device(synth.DB_SEED, synth.READ_SEED, K, cum.ctypes.data_as(C.c_void_p),
+                                          parent.ctypes.data_as(C.c_void_p), parent.size, 0, n, READ_LEN, reads.p, 0))
+    out = DevBuf(n * 4)
+    s = db.sample()
+    s.classify_fixed_device(reads.p.value, READ_LEN, n, d_out=out.p.value)
+    g, u = s.end()
+    st = s.stats()
+    assert st["reads"] == n and int(g.sum()) == n
+    final = out.download(np.uint32, n)
+    assert np.array_equal(np.bincount(final, minlength=g.size), g)
+    # a slice in the middle (it straddles the boundary between the first and the second launch: 67 M reads each)
+    lo = 66_000_000
+    rs, rfinal, _, _ = classify_range(rdb, reads, lo, N_READS)
+    assert np.array_equal(final[lo:lo + N_READS], rfinal)
+    _, f0, _, _ = classify_range(db, full["reads"], 0, N_READS)
+    assert np.array_equal(final[:N_READS], f0)
+    del final
+    # two halves
+    a = db.sample(); a.classify_fixed_device(reads.p.value, READ_LEN, n // 2)
+    b = db.sample(); b.classify_fixed_device(reads.p.value + (n // 2) * READ_LEN, READ_LEN, n - n // 2)
+    ga, gb = a.gcount(), b.gcount()
+    assert np.array_equal(ga + gb, g)
+    nbytes = a.seen_bytes()
+    tmp = DevBuf(nbytes)
+    b.seen_export(0, nbytes, dst_ptr=tmp.p.value, on_device=True)
+    a.seen_or(0, tmp.p.value, nbytes=nbytes, on_device=True)
+    assert np.array_equal(a.ucount_range(0, nbytes * 8), u)
+    for x in (s, rs, a, b):
+        x.close()
+    for x in (tmp, out, reads):
+        x.free()

@@ -500,6 +500,28 @@ def test_seen_bitmap_export_or_and_ranges(seeded):
         s_.close()
 
 
+def test_e2e_unmodified_reference_2pow30_on_gpu(gold_dir):
+    """the _result.txt of the reference program as shipped (2^30 cells; oracle/time_reference.py) on 200 000 seeded pairs"""
+    import gzip
+    import hashlib
+    import json
+    meta = json.load(open(os.path.join(gold_dir, "e2e_ref_full.json")))
+    parent, cnt = synth.load_taxonomy("bact10")
+    cum = synth.cumulative(synth.scaled_counts(cnt, meta["scale"]))
+    keys, targets = synth.db_keys(cum, K)
+    n, L = meta["n_pairs"], meta["read_len"]
+    db = KmerDB(keys, targets, parent, k=K, log2_slots=24)
+    s = db.sample()
+    for r0 in (0, n):  # R1 then R2, two batches
+        s.classify(synth.reads(cum, parent, n, L, K, r0=r0), synth.fixed_offsets(n, L), want_final=False)
+    g, u = s.end()
+    assert s.stats()["lookups"] == meta["lookups"]
+    res = "".join("%d,%d,%d\n" % (i, g[i], u[i]) for i in range(parent.size)).encode()
+    assert hashlib.sha256(res).hexdigest() == meta["result_sha256"]
+    assert res == gzip.open(os.path.join(gold_dir, "e2e_ref_full_result.txt.gz")).read()
+    s.close(); db.close()
+
+
 def test_fmix64_golden_on_gpu(kat):
     """Hashtable::integerHash as the device computes it, against the reference's own values"""
     assert np.array_equal(kmer_id_amd.hash_keys(kat["fmix_in"]), kat["fmix_out"])

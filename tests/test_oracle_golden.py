@@ -129,3 +129,22 @@ def test_e2e_seeded(gold_dir, tmp_path):
     assert res == gzip.open(os.path.join(gold_dir, "e2e_seeded_result.txt.gz")).read()
     assert hashlib.sha256(res).hexdigest() == params["result_sha256"]
     assert hashlib.sha256(open(os.path.join(fq, "big_reads.txt"), "rb").read()).hexdigest() == params["reads_sha256"]
+
+
+def test_e2e_unmodified_reference_2pow30(gold_dir):
+    """oracle/time_reference.py: the reference program as shipped (2^30 cells, 24 GiB) on 200 000 seeded pairs; the
+    oracle (here on all host cores: same counters as sequentially, oracle_selftest.c) must reproduce its _result.txt"""
+    meta = json.load(open(os.path.join(gold_dir, "e2e_ref_full.json")))
+    parent, cnt = synth.load_taxonomy("bact10")
+    cum = synth.cumulative(synth.scaled_counts(cnt, meta["scale"]))
+    keys, targets = synth.db_keys(cum, K)
+    assert keys.size == meta["n_keys"]
+    n, L = meta["n_pairs"], meta["read_len"]
+    bases = np.concatenate([synth.reads(cum, parent, n, L, K, r0=0), synth.reads(cum, parent, n, L, K, r0=n)])
+    db = ob.OracleDB(parent.size, K, 22, parent=parent)
+    db.add(keys, targets)
+    _, g, u, st = db.classify_mt(bases, synth.fixed_offsets(2 * n, L), max(1, len(os.sched_getaffinity(0))))
+    res = "".join("%d,%d,%d\n" % (i, g[i], u[i]) for i in range(parent.size)).encode()
+    assert st["lookups"] == meta["lookups"]
+    assert hashlib.sha256(res).hexdigest() == meta["result_sha256"]
+    assert res == gzip.open(os.path.join(gold_dir, "e2e_ref_full_result.txt.gz")).read()
