@@ -139,8 +139,8 @@ int kid_classify_batch_async(kid_sample *s, const uint8_t *bases, const uint64_t
 int kid_classify_fixed_async(kid_sample *s, const uint8_t *bases, uint32_t read_len, uint64_t n_reads,
                              uint32_t *out_final_targ, uint64_t *ticket);
 int kid_classify_wait(kid_sample *s, uint64_t ticket);
-/* pinned (page-locked) host memory for the buffers above */
-int kid_host_alloc(uint64_t nbytes, void **ptr);
+/* pinned (page-locked) host memory for the buffers above, placed on the NUMA node `device` is attached to */
+int kid_host_alloc(int device, uint64_t nbytes, void **ptr);
 int kid_host_free(void *ptr);
 /* Device-resident form, asynchronous on `stream` (a hipStream_t, NULL = default
  * stream).  A sample has ONE set of scratch buffers: batches handed over on different

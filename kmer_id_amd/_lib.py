@@ -48,7 +48,7 @@ PROTOTYPES = {
     "kid_classify_batch_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, c_u64p]),
     "kid_classify_fixed_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, c_u64p]),
     "kid_classify_wait": (C.c_int, [C.c_void_p, C.c_uint64]),
-    "kid_host_alloc": (C.c_int, [C.c_uint64, c_void_pp]),
+    "kid_host_alloc": (C.c_int, [C.c_int, C.c_uint64, c_void_pp]),
     "kid_host_free": (C.c_int, [C.c_void_p]),
     "kid_classify_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                             C.c_void_p, C.c_void_p]),

@@ -34,10 +34,10 @@ def hash_keys(keys, device=0):
 class PinnedBuffer:
     """Page-locked host memory from the library (kid_host_alloc), viewed as a numpy array."""
 
-    def __init__(self, nbytes):
+    def __init__(self, nbytes, device=0):
         self._lib = _lib.load()
         p = C.c_void_p()
-        check(self._lib.kid_host_alloc(nbytes, C.byref(p)))
+        check(self._lib.kid_host_alloc(device, nbytes, C.byref(p)))
         self.ptr = p.value
         self.nbytes = nbytes
         self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (nbytes,))

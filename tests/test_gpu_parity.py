@@ -547,7 +547,7 @@ def test_seen_bitmaps_merge_across_independent_tables(flags_b):
     # make sure the duplicated keys are hit: implant some of them
     for j, e in enumerate(dup[:2000].tolist()):
         v = int(keys[e])
-        bases[j * L + 40:j * L + 70] = np.frombuffer(bytes("ACGT"[(v >> (2 * (29 - i))) & 3] for i in range(30)).encode(), np.uint8)
+        bases[j * L + 40:j * L + 70] = np.frombuffer("".join("ACGT"[(v >> (2 * (29 - i))) & 3] for i in range(30)).encode(), np.uint8)
     off = synth.fixed_offsets(n, L)
     os_ = ob.OracleSample(odb)
     exp = os_.classify(bases, off)
