@@ -83,6 +83,7 @@ struct kid_sample {
     uint64_t timed_batches = 0;
     // per-batch scratch of the device pipeline (prepare -> pack -> classify), grown on demand
     KidRareArgs *d_rare = nullptr; // device copy, written once in kid_sample_begin (batch_max: by every batch)
+    uint32_t *d_dyn = nullptr;     // chunk counters of the pair kernel's dynamic tail (KID_DYN_SHARDS x 64 bytes)
     uint32_t batch_seq = 0;
     uint64_t reads_submitted = 0; // since the last reset: checked against the device's count when results are read
     // the scratch below is one set per sample: batches on different streams are ordered behind each other
@@ -500,6 +501,7 @@ extern "C" void kid_sample_destroy(kid_sample *s)
     if (s->seen) hipFree(s->seen);
     for (auto &ev : s->timed) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     if (s->d_rare) hipFree(s->d_rare);
+    if (s->d_dyn) hipFree(s->d_dyn);
     if (s->order_ev) hipEventDestroy(s->order_ev);
     if (s->sc_desc) hipFree(s->sc_desc);
     if (s->sc_codes) hipFree(s->sc_codes);
@@ -561,7 +563,14 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
     KID_S_HIP(hipMalloc(&s->seen, s->seen_words * 4));
     KID_S_HIP(hipStreamCreate(&s->stream));
     {
-        const KidRareArgs ra{s->gcount, s->stats, db->d.line_mask, 0u, 0ull, db->rows, s->seen, nullptr, nullptr};
+#ifdef KID_ENDHIST
+        const size_t dyn_bytes = KID_DYN_SHARDS * 64 + 16 * 16384; // + a record per wave (development aid)
+#else
+        const size_t dyn_bytes = KID_DYN_SHARDS * 64;
+#endif
+        KID_S_HIP(hipMalloc(&s->d_dyn, dyn_bytes));
+        KID_S_HIP(hipMemset(s->d_dyn, 0, dyn_bytes));
+        const KidRareArgs ra{s->gcount, s->stats, db->d.line_mask, 0u, s->d_dyn, 0ull, db->rows, s->seen, nullptr, nullptr};
         KID_S_HIP(hipMalloc(&s->d_rare, sizeof(ra)));
         KID_S_HIP(hipMemcpy(s->d_rare, &ra, sizeof(ra), hipMemcpyHostToDevice));
     }
@@ -644,7 +653,7 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     const uint64_t cnt = b.n - r0 < span ? b.n - r0 : span;
     KidPacked pk{s->sc_codes, s->sc_inval, s->sc_desc + r0, b.out_final ? b.out_final + r0 : nullptr, cnt};
     if (r0 != 0) // the kernels find this launch's descriptors and result array in the sample's device struct
-        hipLaunchKernelGGL(kid_rebase_kernel, dim3(1), dim3(1), 0, stream, s->d_rare, pk.desc, pk.out_final);
+        hipLaunchKernelGGL(kid_rebase_kernel, dim3(1), dim3(64), 0, stream, s->d_rare, pk.desc, pk.out_final);
 #define KID_LAUNCH1(R, H, M, KF, PK)                                                                                            \
     hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, KF, PK>), dim3(grid), dim3(block),                                     \
                        (((H) ? ((PK) ? hist_words16 : hist_words) : 0u) +                                                       \
@@ -1127,6 +1136,17 @@ extern "C" int kid_sample_debug_counters(kid_sample *s, uint64_t out[24])
     if (rc != KID_OK) return rc;
     KID_HIP(hipDeviceSynchronize());
     KID_HIP(hipMemcpy(out, s->stats + 8, 24 * 8, hipMemcpyDeviceToHost));
+    return KID_OK;
+}
+
+// development aid (KID_ENDHIST builds): the per-wave records of the last launch
+extern "C" int kid_sample_debug_wave_records(kid_sample *s, uint32_t *out, uint64_t n_waves)
+{
+    if (!s || !out) return kid_fail(KID_ERR_ARG, "null argument");
+    int rc = kid_use_device(s->db->device);
+    if (rc != KID_OK) return rc;
+    KID_HIP(hipDeviceSynchronize());
+    KID_HIP(hipMemcpy(out, s->d_dyn + KID_DYN_SHARDS * 16, n_waves * 16, hipMemcpyDeviceToHost));
     return KID_OK;
 }
 

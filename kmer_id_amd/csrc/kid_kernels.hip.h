@@ -25,7 +25,22 @@
 // results of 64 reads
 #define KID_CQ_CAP 192   // a read appends at most 128 entries to fewer than KID_CQ_FLUSH queued ones
 #define KID_CQ_FLUSH 64
-#define KID_PAIR_LDS_WORDS (4 + 3 * KID_CQ_CAP + KID_CQ_CAP / 4 + 64)
+#define KID_PAIR_LDS_WORDS (4 + 3 * KID_CQ_CAP + KID_CQ_CAP / 4 + 64 + 128) // ... + the batch read numbers of 128 result slots
+#ifndef KID_DYNAMIC
+// 1: the waves of the pair kernel draw their reads in small blocks from counters instead of owning a fixed share.
+// Measured (profiles/r02/dynamic_blocks.txt): the SIMDs serve their oldest waves first, so with fixed shares the waves of
+// a 2 M-read launch finish anywhere between 45 % and 100 % of the launch -- but handing the work out dynamically did
+// not shorten the launch: the starved (young) waves hold their last blocks for hundreds of microseconds, and every
+// block switch costs a drain.  Off by default; the code stays for the next attempt.
+#define KID_DYNAMIC 0
+#endif
+#define KID_DYN_SHARDS 16u // counters the chunks are drawn from (one word takes ~90 fetches per microsecond)
+#ifndef KID_DYN_CHUNK
+#define KID_DYN_CHUNK 16u  // most reads a wave draws at a time (even)
+#endif
+#ifndef KID_DYN_MAXLEFT
+#define KID_DYN_MAXLEFT 96u // at most this many reads per wave are left to the pool
+#endif
 #define KID_GEN_ML_LDS_WORDS (104 + 3 * KID_CQ_CAP + KID_CQ_CAP / 4 + 64) // general loops on the minimizer-localised table: strip, counters, queue, results
 #if defined(KID_ABLATE) && KID_ABLATE >= 2
 #define KID_ABLATE_NOMIN 1
@@ -122,6 +137,7 @@ struct KidRareArgs {
     unsigned long long *stats;
     uint32_t line_mask;
     uint32_t pad;
+    uint32_t *dyn; // KID_DYN_SHARDS chunk counters, 64 bytes apart; zeroed for every launch
     unsigned long long batch_max; // (batch sequence number << 32) | largest n_kmers of the batch: kid_prepare_kernel
     // what the resolver / the 64-read flush of the pair kernels need (rare paths by now, bulk work: a scalar
     // load there is cheaper than four scalar registers held across the hot loop)
@@ -302,6 +318,7 @@ __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, u
         rare->out_final = b.out_final;
         rare->desc = desc;
     }
+    if (blockIdx.x == 0 && threadIdx.x < KID_DYN_SHARDS) rare->dyn[threadIdx.x * 16u] = 0;
     uint32_t bad = 0, mx = 0;
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < b.n; r += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t off;
@@ -354,8 +371,11 @@ __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, u
 // a batch classified in several launches: the next launch's share of the descriptors and of the result array
 __global__ void kid_rebase_kernel(KidRareArgs *rare, const KidReadDesc *desc, uint32_t *out_final)
 {
-    rare->desc = desc;
-    rare->out_final = out_final;
+    if (threadIdx.x == 0) {
+        rare->desc = desc;
+        rare->out_final = out_final;
+    }
+    if (threadIdx.x < KID_DYN_SHARDS) rare->dyn[threadIdx.x * 16u] = 0;
 }
 
 // ASCII -> 2 bits per base + invalid mask for the whole batch buffer, 16 bases per lane
@@ -412,13 +432,31 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         if (mode != PAIRK) return;
     }
     if (threadIdx.x == 0) atomicMin(&s.stats[30], (unsigned long long)__builtin_amdgcn_s_memrealtime());
-#if defined(KID_STAGGER) && KID_STAGGER > 0
-    // experiment: the waves of a SIMD start out of phase (1: the second half of a workgroup's waves half a trip
-    // later; 2: eight phases from wave number and workgroup), so that one wave's front half meets another's wait
+#ifdef KID_WAVEPROF // development aid: when do the waves of a launch pass their 64th, 128th ... read, and when do they end?
+    unsigned long long wp_t0 = __builtin_amdgcn_s_memrealtime(), wp_prev = wp_t0;
+    uint32_t wp_q = 0;
+#endif
+#if defined(KID_PRIO) && KID_PRIO > 0
+    // experiment: the SIMD's issue arbitration prefers its older waves (those finish first, the rest of the kernel
+    // runs at a falling occupancy); 1: the second-dispatched half of a workgroup's waves gets static priority 1,
+    // 2: priority by wave number within its SIMD pair and workgroup parity
     if (PAIRK == 1) {
         const uint32_t w8 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        uint32_t ph = (KID_STAGGER == 1) ? ((w8 >> 2) & 1u) * 4u : (((w8 >> 2) & 1u) * 4u + ((blockIdx.x * 0x9E3779B1u) >> 30));
-        for (uint32_t q = 0; q < ph * 3u; q++) __builtin_amdgcn_s_sleep(14); // 3 x 14 x 64 cycles = 1/8 of a ~21 k-cycle trip
+        if (KID_PRIO == 1) { if (w8 >= 4u) __builtin_amdgcn_s_setprio(1); }
+        else if (KID_PRIO == 2) { if (((w8 >> 2) ^ blockIdx.x) & 1u) __builtin_amdgcn_s_setprio(1); }
+        else if (KID_PRIO == 3) { if (w8 >= 4u) __builtin_amdgcn_s_setprio(3); }
+        else if (KID_PRIO == 4) { // the later a workgroup was dispatched, the higher its priority (blockIdx / CUs = its age class)
+            const uint32_t cls = blockIdx.x >> 8;
+            if (cls == 1u) __builtin_amdgcn_s_setprio(1);
+            else if (cls == 2u) __builtin_amdgcn_s_setprio(2);
+            else if (cls >= 3u) __builtin_amdgcn_s_setprio(3);
+        }
+        else if (KID_PRIO == 5) { // the same, inverted (control)
+            const uint32_t cls = blockIdx.x >> 8;
+            if (cls == 0u) __builtin_amdgcn_s_setprio(3);
+            else if (cls == 1u) __builtin_amdgcn_s_setprio(2);
+            else if (cls == 2u) __builtin_amdgcn_s_setprio(1);
+        }
     }
 #endif
     // (descs == b.desc, passed once more as a restrict-qualified argument: the wave-uniform
@@ -747,10 +785,11 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
     const uint32_t gw32 = (uint32_t)gw, nw32 = (uint32_t)nw; // 32-bit read indices (n < 2^31): read number i of this wave is gw + i nw
     uint64_t rb_skip = 0;   // result slots of the current block of 64 reads that are not this pass's to store
     bool rb_direct = false; // second pass of the general loops (reads of more than one segment): results stored at once
+    uint32_t *const RG = RB + 64; // pair kernel: which read of the batch a result slot belongs to (128 slots: the next block's are known early)
     auto flush_results = [&](const uint32_t i0, const uint32_t n) { // this wave's reads i0 .. i0+n-1 (n <= 64)
         uint32_t *const outp = rare->out_final;
         if (outp && lane < n && !((rb_skip >> ((i0 + lane) & 63u)) & 1ull))
-            kid_store_u32_nowait(&outp[gw32 + (i0 + lane) * nw32], RB[(i0 + lane) & 63u]);
+            kid_store_u32_nowait(&outp[PAIRK == 1 ? RG[(i0 + lane) & 127u] : gw32 + (i0 + lane) * nw32], RB[(i0 + lane) & 63u]);
         rb_skip = 0;
         RB[lane] = 0; // (a read without any hit does not write its slot: see commit_zero)
     };
@@ -1096,6 +1135,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         if (!prefetched) prefetch();
         KID_TICK(5);
     };
+    uint32_t reads_done = gw < b.n ? (uint32_t)((b.n - gw + nw - 1) / nw) : 0u; // the wave's strided share (the pair kernel counts its own)
 #if KID_PAIRS
     // ---- batches whose reads all fit one group (<= U*64 k-mers: Illumina reads): hand-pipelined pairs.
     // A wave is a chain of dependent round trips (strip, header, hit cell, ancestor row) that eight waves
@@ -1112,14 +1152,20 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         // descriptors, 64 at a time: lane l holds the one of read number blk + l of this wave -- the low word
         // of first_base, and its high word (< 2^16: a batch is smaller than 2^48 bytes) with n_kmers (<= 128
         // in this kernel) above it
+        // A wave works through SEGMENTS of reads: read j of a segment is read seg_first + j seg_stride of the batch and
+        // has the wave-local number seg_seq0 + j (tags and result slots go by wave-local numbers, which simply run on
+        // from segment to segment).  The duo kernel has one segment: the wave's strided share of the batch.
         uint32_t blk = 0, dv_lo = 0, dv_hn = 0;
+        uint32_t seg_first = gw32, seg_stride = nw32, seg_seq0 = 0, seg_end = cnt;
         auto load_block = [&]() {
-            const uint64_t rr = gw + (uint64_t)(blk + lane) * nw;
+            const uint32_t sq = blk + lane; // wave-local number
             dv_lo = 0; dv_hn = 0;
-            if (rr < b.n) {
+            if (sq < seg_end) {
+                const uint32_t rr = seg_first + (sq - seg_seq0) * seg_stride;
                 const KidReadDesc d = static_cast<const KidReadDesc *>(rare->desc)[rr];
                 dv_lo = (uint32_t)d.first_base;
                 dv_hn = ((uint32_t)(d.first_base >> 32) & 0xFFFFu) | ((d.n_kmers > 0 ? (uint32_t)d.n_kmers : 0u) << 16) | ((d.pad & 1u) << 31);
+                if (PAIRK == 1) RG[sq & 127u] = rr;
             }
         };
         auto issue_words = [&](const uint32_t idx, uint32_t &c, uint32_t &iv) {
@@ -1141,11 +1187,11 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
             return v;
         };
-        load_block();
         uint32_t cA, iA, cB, iB;
-        issue_words(0u, cA, iA);
-        issue_words(1u, cB, iB);
         if constexpr (PAIRK == 2) {
+            load_block();
+            issue_words(0u, cA, iA);
+            issue_words(1u, cB, iB);
             // ---- reads of two groups (129..256 k-mers: 2 x 250 bp): the pair is the two groups of ONE read.
             // They share the read's packed words, their queue entries carry the same tag, and the read
             // stays open in the resolver between them.  Two word sets alternate, each requested two trips
@@ -1191,16 +1237,120 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             if (cnt & 63u) flush_results(cnt & ~63u, cnt & 63u);
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(cA), "+v"(iA), "+v"(cB), "+v"(iB) : : "memory");
         } else {
-        for (uint32_t i = 0; i < cnt; i += 2) {
+        // Which reads a wave classifies is not fixed in advance.  The SIMD's issue arbitration prefers its older waves,
+        // so with equal shares the waves of a launch finish far apart (2 M reads: the mean wave was through after 1.0 ms,
+        // the last one after 1.5 ms, the launch ending at a falling occupancy).  Instead a wave draws BLOCKS of consecutive
+        // reads from a counter -- 16 reads at a time, fewer as its counter's pool runs dry -- one block ahead of the one
+        // it is working on: the fetch-and-add for the block after the next is in flight while a block is classified, and
+        // the descriptors of the next block are loaded during the block's last pair, like those of a wave's next 64 reads
+        // were before.  KID_DYN_SHARDS counters (64 bytes apart) share the reads of a launch evenly; the workgroups of all
+        // XCDs take turns on a counter (blockIdx >> 3).  KID_DYNAMIC = 0: the old strided shares, blocks of 64.
+        const uint32_t n32 = (uint32_t)b.n;
+#ifdef KID_DYN_SHARD_HASH
+        const uint32_t sh = ((blockIdx.x * 0x9E3779B1u) >> 16) & (KID_DYN_SHARDS - 1u);
+#else
+        const uint32_t sh = (blockIdx.x >> 3) & (KID_DYN_SHARDS - 1u);
+#endif
+        const uint32_t sp = (((n32 + KID_DYN_SHARDS - 1u) / KID_DYN_SHARDS) + 1u) & ~1u; // reads per counter (even)
+        uint32_t cur_sh = sh;                                                             // the counter the wave draws from
+        uint32_t s0 = sh * sp < n32 ? sh * sp : n32;
+        uint32_t s1 = s0 + sp < n32 ? s0 + sp : n32;                                      // that counter's reads: [s0, s1)
+        const uint32_t shard_waves = ((gridDim.x + 8u * KID_DYN_SHARDS - 1u) / (8u * KID_DYN_SHARDS)) * 8u * wpb; // (upper bound)
+        uint32_t *ctr = rare->dyn + sh * 16u;
+        auto guided = [&](const uint32_t left) -> uint32_t { // smaller blocks towards the end of a pool, so that the waves finish together
+            uint32_t t = left / (2u * shard_waves);
+            t = t > KID_DYN_CHUNK ? KID_DYN_CHUNK : t;
+            return t < 2u ? 2u : (t & ~1u);
+        };
+        uint32_t seq = 0;        // wave-local number of the pair's first read (even)
+        uint32_t blen = 0;       // reads in the current block [blk, blk + blen)
+        uint32_t nreal = 0;      // reads classified
+        uint32_t take = guided(s1 - s0); // reads the next fetch-and-add asks for
+        uint32_t gv = 0;         // lane 0: what the fetch-and-add in flight returned = first read of the block after the next
+        uint32_t sblk = 0;       // KID_DYNAMIC = 0: number of the wave's next strided block
+        // The next block: its first read, stride and length (0: none) -- dynamic: from the fetch-and-add that has been in
+        // flight since the block before (gv) -- then its descriptors; the fetch-and-add for the block after it goes out
+        // while those are on their way.  Descriptors: lane l holds the one of wave-local read blk + l.
+        auto switch_block = [&]() {
+            uint32_t first, stride, len;
+            bool again = false;
+            if (KID_DYNAMIC) {
+                uint32_t st = s0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)gv);
+                bool have = st < s1;
+                if (!have) {
+                    // This counter's reads are gone: on to the others'.  The waves of old workgroups are served first by
+                    // their SIMDs, so the pools do not run dry together; without this the waves of a fast pool would idle
+                    // through the rest of the launch.  A look before the fetch-and-add: at the end of a launch every
+                    // wave comes by here, and sixteen fetch-and-adds each would queue up on the counters.
+                    for (uint32_t kk = 1; kk < KID_DYN_SHARDS && !have; kk++) {
+                        const uint32_t s2 = (cur_sh + kk) & (KID_DYN_SHARDS - 1u);
+                        const uint32_t a0 = s2 * sp < n32 ? s2 * sp : n32, a1 = a0 + sp < n32 ? a0 + sp : n32;
+                        uint32_t *const c2 = rare->dyn + s2 * 16u;
+                        const uint32_t seen_v = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        if (seen_v >= a1 - a0) continue;
+                        const uint32_t t2 = guided(a1 - a0 - seen_v);
+                        uint32_t g2 = 0;
+                        if (lane == 0) g2 = atomicAdd(c2, t2);
+                        g2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g2);
+                        if (g2 < a1 - a0) { cur_sh = s2; s0 = a0; s1 = a1; ctr = c2; st = a0 + g2; take = t2; have = true; }
+                    }
+                }
+                len = 0;
+                if (have) {
+                    len = s1 - st < take ? s1 - st : take; // (take: what the fetch-and-add that returned st asked for)
+                    take = guided(s1 - st);
+                    again = true;
+                }
+                first = st;
+                stride = 1u;
+            } else {
+                const uint32_t j0 = sblk * 64u;
+                sblk++;
+                first = gw32 + j0 * nw32;
+                stride = nw32;
+                len = j0 < cnt ? (cnt - j0 < 64u ? cnt - j0 : 64u) : 0u;
+            }
+            KidReadDesc d;
+            d.first_base = 0; d.n_kmers = 0; d.pad = 0;
+            const uint32_t rr = first + lane * stride;
+            if (lane < len) d = static_cast<const KidReadDesc *>(rare->desc)[rr];
+            if (KID_DYNAMIC && again) { gv = 0; if (lane == 0) gv = atomicAdd(ctr, take); }
+            dv_lo = (uint32_t)d.first_base;
+            dv_hn = ((uint32_t)(d.first_base >> 32) & 0xFFFFu) | ((d.n_kmers > 0 ? (uint32_t)d.n_kmers : 0u) << 16) | ((d.pad & 1u) << 31);
+            if (lane < len) RG[(blk + lane) & 127u] = rr;
+            blen = len;
+        };
+        if (KID_DYNAMIC) {
+            if (lane == 0 && s0 < s1) gv = atomicAdd(ctr, take);
+        }
+#ifdef KID_ENDHIST
+        uint32_t eh_last = 0, eh_nblk = 1;
+#endif
+        switch_block();
+        bool more = blen != 0;
+        if (more) {
+            issue_words(0u, cA, iA);
+            issue_words(1u, cB, iB);
+        }
+        while (more) {
+            const uint32_t i = seq;
             const uint32_t ia = i - blk;
             const uint32_t hnA = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)ia), hnB = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)(ia + 1u));
             const uint32_t nkA = (hnA >> 16) & 0x7FFFu, nkB = (hnB >> 16) & 0x7FFFu;
             const uint32_t shA = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)ia) & 15u;
             const uint32_t shB = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)(ia + 1u)) & 15u;
+            const bool realB = ia + 1u < blen; // (a block with an odd number of reads -- the last of a pool: B is a phantom of zero k-mers)
             KidGroup<U> gA, gB;
             uint32_t badA = 0, badB = 0;
-            // the next descriptor block, if the next pair is not in this one (this pair's are in scalars by now)
-            if (ia + 3u > 63u) { blk = i + 2u; load_block(); }
+            // the block's last pair: the next block's descriptors (this pair's are in scalars by now)
+            if (ia + 2u >= blen) {
+                blk = i + 2u;
+                switch_block(); // (no block: all-zero descriptors, the word requests below fetch what nobody needs)
+                more = blen != 0;
+#ifdef KID_ENDHIST
+                if (more) { eh_last = (uint32_t)(__builtin_amdgcn_s_memrealtime() - rare->stats[30]); eh_nblk++; }
+#endif
+            }
 
             // The packed words of the next pair are requested as soon as this pair's are used up, a whole
             // trip ahead: they come from HBM (the packed image of a batch is larger than the L2).
@@ -1233,20 +1383,60 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             KID_TICK(6);
             gB.hd[0] = make_uint4(hB0.x, hB0.y, hB0.z, hB0.w);
             gB.hd[1] = make_uint4(hB1.x, hB1.y, hB1.z, hB1.w);
-            if (i + 1u < cnt) { // (a wave with an odd number of reads: B is a phantom of zero k-mers)
+            nreal += realB ? 2u : 1u;
+            if (realB) {
                 n_lookups += nkB - badB;
                 if (!back_deferred(gB, i + 1u)) commit_zero(i + 1u);
                 else if (qn >= KID_CQ_FLUSH) resolve_all(i + 1u, 0xFFFFFFFFu);
             }
             KID_TICK(7);
-            if (((i + 2u) & 63u) == 0u) { // tags and result slots are read numbers mod 64
+            seq = i + 2u;
+            if ((seq & 63u) == 0u) { // tags and result slots are wave-local read numbers mod 64
                 if (qn) resolve_all(i + 1u, 0xFFFFFFFFu);
-                flush_results(i + 2u - 64u, 64u);
+                flush_results(seq - 64u, 64u);
+#ifdef KID_WAVEPROF
+                {
+                    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+                    if (lane == 0 && wp_q < 4u) atomicAdd(&rare->stats[8 + wp_q], t - wp_prev); // time for reads 64q .. 64q+63
+                    wp_prev = t;
+                    wp_q++;
+                }
+#endif
             }
         }
-        if (qn) resolve_all(cnt - 1u, 0xFFFFFFFFu);
-        if (cnt & 63u) flush_results(cnt & ~63u, cnt & 63u);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cA), "+v"(iA), "+v"(cB), "+v"(iB) : : "memory");
+        // (the two requests behind the last pair fetched words nobody needs; a fetch-and-add may still be out)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cA), "+v"(iA), "+v"(cB), "+v"(iB), "+v"(gv) : : "memory");
+        // a block of odd length ends the wave's work: seq counts its phantom, the flush below must not
+        if (nreal & 1u) seq -= 1u;
+        reads_done = seq;
+        if (qn) resolve_all(seq - 1u, 0xFFFFFFFFu);
+        if (seq & 63u) flush_results(seq & ~63u, seq & 63u);
+#ifdef KID_ENDHIST // development aid: when do the waves of a launch run out of reads?  24 bins of 64 us + a record per wave
+        if (lane == 0) {
+            const unsigned long long rel = __builtin_amdgcn_s_memrealtime() - rare->stats[30];
+            const unsigned long long bin = rel / 6400ull;
+            atomicAdd(&rare->stats[8 + (bin < 23ull ? bin : 23ull)], 1ull);
+            uint32_t *rec = rare->dyn + KID_DYN_SHARDS * 16u + 4u * (uint32_t)gw;
+            rec[0] = seq;                 // reads classified
+            rec[1] = (uint32_t)rel;       // end of its loop, 10 ns ticks from the launch's first workgroup start
+            rec[2] = eh_last;             // start of its last block
+            rec[3] = eh_nblk;             // blocks drawn
+        }
+#endif
+#ifdef KID_WAVEPROF
+        if (lane == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            atomicAdd(&rare->stats[12], t - wp_prev);                      // the reads behind the last full block of 64
+            atomicAdd(&rare->stats[13], t - wp_t0);                        // sum of wave lifetimes (loop only)
+            atomicMin(&rare->stats[14], t - rare->stats[30]);              // first wave through, relative to the kernel's first start
+            atomicMax(&rare->stats[15], t - rare->stats[30]);              // last wave through
+            atomicAdd(&rare->stats[16], wp_t0 - rare->stats[30]);          // sum of wave start delays
+            atomicMax(&rare->stats[17], wp_t0 - rare->stats[30]);          // last wave to start
+            // histogram of end times, 16 bins of 10 us from 0.9 ms
+            const unsigned long long rel = t - rare->stats[30];
+            atomicAdd(&rare->stats[18], (unsigned long long)(rel * rel / 100ull)); // sum of squares (in 100 ns^2 units)
+        }
+#endif
         }
     }
 #endif
@@ -1321,7 +1511,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
 #endif
     if (threadIdx.x == 0) atomicMax(&s.stats[31], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     if (lane == 0) {
-        const unsigned long long tl = *WL, n_reads = gw < b.n ? (b.n - gw + nw - 1) / nw : 0ull; // reads r = gw + i nw
+        const unsigned long long tl = *WL, n_reads = reads_done;
         const uint32_t n_hits = WC[2];
         const unsigned long long te = WC[3];
         if (n_reads) atomicAdd(&rare->stats[0], n_reads);
