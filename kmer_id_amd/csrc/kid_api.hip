@@ -630,12 +630,17 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     // and queues.  Minimizer-localised table: two 16-bit counters per word, so a workgroup must stay below 65536
     // reads per launch -- a larger batch is classified in several launches of the same grid (`span` reads each).
     const bool ml = db->d.minloc != 0;
-    const int grid = kid_grid_for(b.n, wpb, db->num_cu * 4);
+    // Workgroups per CU in the grid.  Four are resident; the SIMDs serve their oldest waves first, so equal shares
+    // finish far apart (45 % .. 100 % of a launch) and a grid of exactly the resident workgroups ends at a falling
+    // occupancy.  With 16 per CU the dispatcher hands a new workgroup to a CU whenever one is through: 0.97 instead of
+    // 1.02 ms per 2 M reads (profiles/r02/ab_grid_mult.txt).  KID_GRID_MULT overrides (experiments).
+    static const int grid_mult = getenv("KID_GRID_MULT") ? atoi(getenv("KID_GRID_MULT")) : 16;
+    const int grid = kid_grid_for(b.n, wpb, db->num_cu * (grid_mult > 0 ? grid_mult : 16));
     const uint32_t hist_words32 = (ntar + 3u) & ~3u, hist_words16 = ((ntar + 1u) / 2u + 3u) & ~3u;
     const uint32_t hist_words = ml ? hist_words16 : hist_words32;
     const uint32_t wave_words = ml ? KID_GEN_ML_LDS_WORDS : KID_WAVE_LDS_WORDS;
-    const bool hist = (hist_words + wpb * wave_words) * 4u <= 40u * 1024u;
-    const bool hist_pair = (hist_words16 + wpb * KID_PAIR_LDS_WORDS) * 4u <= 40u * 1024u;
+    const bool hist = (hist_words + wpb * wave_words) * 4u + 32u <= 40u * 1024u;
+    const bool hist_pair = (hist_words16 + wpb * KID_PAIR_LDS_WORDS) * 4u + 32u <= 40u * 1024u;
     uint64_t span = b.n;
     if (ml && (hist || hist_pair)) {
         const uint64_t cap = (uint64_t)grid * (65535u - 2u * (uint32_t)wpb); // reads per launch: < 65536 per workgroup
@@ -657,7 +662,7 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
 #define KID_LAUNCH1(R, H, M, KF, PK)                                                                                            \
     hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, KF, PK>), dim3(grid), dim3(block),                                     \
                        (((H) ? ((PK) ? hist_words16 : hist_words) : 0u) +                                                       \
-                        (size_t)wpb * ((PK) ? KID_PAIR_LDS_WORDS : wave_words)) * 4, stream,                                   \
+                        (size_t)wpb * ((PK) ? KID_PAIR_LDS_WORDS : wave_words)) * 4 + 32, stream,                              \
                        db->d, pk, sd, (H) ? ((PK) ? hist_words16 : hist_words) : 0u, pk.desc, s->d_rare)
 #define KID_LAUNCH(R, H, M)                                                                                                    \
     do {                                                                                                                       \

@@ -468,10 +468,15 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
     uint32_t *hist = kid_smem;
     uint32_t *WA = kid_smem + hist_words + wib * (PAIRK ? KID_PAIR_LDS_WORDS : MINLOC ? KID_GEN_ML_LDS_WORDS : KID_WAVE_LDS_WORDS); // strip: 66 packed words + 34 mask words
 
+    // the workgroup's totals for kid_sample_stats (behind the waves' areas): one set of global atomics per workgroup --
+    // four per WAVE, all on one line, were 32 768 atomics per launch queueing up on one L2 atomic unit (~0.1 ms)
+    unsigned long long *const WGS = reinterpret_cast<unsigned long long *>(
+        kid_smem + hist_words + wpb * (PAIRK ? KID_PAIR_LDS_WORDS : MINLOC ? KID_GEN_ML_LDS_WORDS : KID_WAVE_LDS_WORDS));
+    if (threadIdx.x < 4) WGS[threadIdx.x] = 0;
     if (HIST) {
         for (uint32_t i = threadIdx.x; i < hist_words; i += blockDim.x) hist[i] = 0;
-        __syncthreads();
     }
+    __syncthreads();
 
     const int k = KFIX ? KFIX : db.k; // KFIX = 30: the reference's KSIZE folded into the shifts and masks
     const uint32_t win = (uint32_t)kid_min_window(k); // m-mers per k-mer window: 15 or 16
@@ -1509,16 +1514,21 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
 #ifdef KID_ABLATE
     if (sink == 0x12345678u) atomicAdd(&rare->stats[7], 1ull);
 #endif
-    if (threadIdx.x == 0) atomicMax(&s.stats[31], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     if (lane == 0) {
         const unsigned long long tl = *WL, n_reads = reads_done;
         const uint32_t n_hits = WC[2];
         const unsigned long long te = WC[3];
-        if (n_reads) atomicAdd(&rare->stats[0], n_reads);
-        if (tl) atomicAdd(&rare->stats[1], tl);
-        if (tl + te) atomicAdd(&rare->stats[2], tl + te); // cells read: one per lookup plus the probes beyond the first
-        if (n_hits) atomicAdd(&rare->stats[3], (unsigned long long)n_hits);
+        if (n_reads) atomicAdd(&WGS[0], n_reads);
+        if (tl) atomicAdd(&WGS[1], tl);
+        if (tl + te) atomicAdd(&WGS[2], tl + te); // cells read: one per lookup plus the probes beyond the first
+        if (n_hits) atomicAdd(&WGS[3], (unsigned long long)n_hits);
     }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const unsigned long long v = WGS[threadIdx.x];
+        if (v) atomicAdd(&rare->stats[threadIdx.x], v);
+    }
+    if (threadIdx.x == 0) atomicMax(&s.stats[31], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 // ------------------------------------------------------------------ unit probes (parity tests)
