@@ -92,6 +92,8 @@ int kid_db_build(const uint64_t *keys, const uint32_t *targets, uint64_t n,
 int kid_db_build_device(const void *d_keys, const void *d_targets, uint64_t n,
                         const int32_t *parent, int32_t ntar, int k, int log2_slots,
                         int max_probes, uint32_t flags, int device, kid_db **out);
+/* a replica of `src` in the HBM of `device` (device-to-device copies; the reference, pinned into every GPU) */
+int kid_db_replicate(const kid_db *src, int device, kid_db **out);
 int kid_db_get_info(const kid_db *db, kid_db_info *out);
 void kid_db_destroy(kid_db *db);
 
@@ -164,6 +166,11 @@ int kid_trim_batch(kid_db *db, const uint8_t *quals, const uint64_t *offsets, ui
  * gcount[ntar], ucount[ntar] as written to <prefix>_result.txt (:1040-1043).
  * Synchronises the sample's outstanding work first.                             */
 int kid_sample_end(kid_sample *s, int64_t *gcount, int64_t *ucount);
+/* The same for ONE sample whose batches were dealt out over n kid_sample objects, one per GPU, each on its own
+ * replica of the database (kid_db_replicate): gcount summed, ucount from the union of the seen-bitmaps (copied peer
+ * to peer to samples[0]'s GPU).  Replaces the per-sample reset + write of main (newkmer_10nx.cpp:1015-1045) around
+ * N devices; the result is identical for any N and any way of dealing the batches.                              */
+int kid_sample_end_merged(kid_sample **samples, int n, int64_t *gcount, int64_t *ucount);
 /* {reads, k-mer lookups, table cells read, k-mer hits} so far (synchronises) */
 int kid_sample_stats(kid_sample *s, uint64_t out[4]);
 

@@ -5,6 +5,6 @@ package is the thin Python host layer used by the tests, the benchmark and the
 multi-GPU launcher.
 """
 from ._lib import KidError, KID_FLAG_HOST_BUILD, KID_FLAG_REF_GEOMETRY, KID_FLAG_U_IS_T, device_count, load  # noqa: F401
-from .api import KmerDB, PinnedBuffer, Sample, hash_keys  # noqa: F401
+from .api import KmerDB, PinnedBuffer, Sample, end_merged, hash_keys  # noqa: F401
 
-__all__ = ["KmerDB", "Sample", "PinnedBuffer", "hash_keys", "KidError", "device_count", "load", "KID_FLAG_U_IS_T", "KID_FLAG_HOST_BUILD", "KID_FLAG_REF_GEOMETRY"]
+__all__ = ["KmerDB", "Sample", "PinnedBuffer", "hash_keys", "end_merged", "KidError", "device_count", "load", "KID_FLAG_U_IS_T", "KID_FLAG_HOST_BUILD", "KID_FLAG_REF_GEOMETRY"]

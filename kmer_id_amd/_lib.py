@@ -36,6 +36,7 @@ PROTOTYPES = {
                                C.c_uint32, C.c_int, c_void_pp]),
     "kid_db_build_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.c_int, C.c_int,
                                       C.c_int, C.c_uint32, C.c_int, c_void_pp]),
+    "kid_db_replicate": (C.c_int, [C.c_void_p, C.c_int, c_void_pp]),
     "kid_db_get_info": (C.c_int, [C.c_void_p, C.POINTER(KidDbInfo)]),
     "kid_db_destroy": (None, [C.c_void_p]),
     "kid_db_lookup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
@@ -55,6 +56,7 @@ PROTOTYPES = {
     "kid_classify_fixed_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
     "kid_trim_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kid_sample_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kid_sample_end_merged": (C.c_int, [c_void_pp, C.c_int, C.c_void_p, C.c_void_p]),
     "kid_sample_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kid_sample_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "kid_sample_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), c_u64p]),

@@ -84,6 +84,15 @@ class KmerDB:
         self._lib = lib
         return self
 
+    def replicate(self, device):
+        """A replica of this database in the HBM of `device` (device-to-device copies)."""
+        other = KmerDB.__new__(KmerDB)
+        h = C.c_void_p()
+        check(self._lib.kid_db_replicate(self._h, device, C.byref(h)))
+        other._h = h
+        other._lib = self._lib
+        return other
+
     @property
     def info(self):
         out = KidDbInfo()
@@ -137,6 +146,18 @@ class KmerDB:
             self.close()
         except Exception:
             pass
+
+
+def end_merged(samples):
+    """One sample of the input dealt out over several Sample objects (one per GPU / replica) -> (gcount, ucount)."""
+    lib = _lib.load()
+    n = len(samples)
+    arr = (C.c_void_p * n)(*[s._h for s in samples])
+    ntar = samples[0].ntar
+    g = np.empty(ntar, np.int64)
+    u = np.empty(ntar, np.int64)
+    check(lib.kid_sample_end_merged(arr, n, _ptr(g), _ptr(u)))
+    return g, u
 
 
 class Sample:

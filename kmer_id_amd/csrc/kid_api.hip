@@ -414,6 +414,59 @@ extern "C" int kid_db_build_device(const void *d_keys, const void *d_targets, ui
     return kid_db_build_common(nullptr, nullptr, d_keys, d_targets, n, parent, ntar, k, log2_slots, max_probes, flags, device, out);
 }
 
+// A replica of a database on another GPU (or on the same one): device-to-device copies of the table (16 GiB at bact10
+// scale: over xGMI between peers), the taxonomy arrays and the entry -> target map.  Entry ordinals are part of the
+// cells, so the replicas' samples share one seen-bitmap numbering (kid_sample_end_merged).
+extern "C" int kid_db_replicate(const kid_db *src, int device, kid_db **out)
+{
+    if (!src || !out) return kid_fail(KID_ERR_ARG, "null argument");
+    *out = nullptr;
+    int rc = kid_use_device(device);
+    if (rc != KID_OK) return rc;
+    kid_db *db = new kid_db();
+    db->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) db->num_cu = prop.multiProcessorCount;
+    if (db->num_cu <= 0) db->num_cu = 256;
+    const size_t nt = (size_t)src->info.ntar;
+#define KID_R_HIP(call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            kid_db_destroy(db);                                                                  \
+            return kid_fail(e_ == hipErrorOutOfMemory ? KID_ERR_NOMEM : KID_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+        }                                                                                        \
+    } while (0)
+    auto copy = [&](void *dst, const void *from, size_t nbytes) -> hipError_t {
+        if (device == src->device) return hipMemcpy(dst, from, nbytes, hipMemcpyDeviceToDevice);
+        return hipMemcpyPeer(dst, device, from, src->device, nbytes);
+    };
+    KID_R_HIP(hipMalloc(&db->table, src->info.table_bytes));
+    KID_R_HIP(copy(db->table, src->table, src->info.table_bytes));
+    KID_R_HIP(hipMalloc(&db->parent, sizeof(int32_t) * nt));
+    KID_R_HIP(copy(db->parent, src->parent, sizeof(int32_t) * nt));
+    KID_R_HIP(hipMalloc(&db->depth, sizeof(int32_t) * nt));
+    KID_R_HIP(copy(db->depth, src->depth, sizeof(int32_t) * nt));
+    if (src->rows) {
+        KID_R_HIP(hipMalloc(&db->rows, sizeof(uint4) * nt));
+        KID_R_HIP(copy(db->rows, src->rows, sizeof(uint4) * nt));
+    }
+    db->seen_bits = src->seen_bits;
+    KID_R_HIP(hipMalloc(&db->ord_target, db->seen_bits * 4));
+    KID_R_HIP(copy(db->ord_target, src->ord_target, db->seen_bits * 4));
+    KID_R_HIP(hipDeviceSynchronize());
+#undef KID_R_HIP
+    db->d = src->d;
+    db->d.table = db->table;
+    db->d.rows = db->rows;
+    db->d.parent = db->parent;
+    db->d.depth = db->depth;
+    db->info = src->info;
+    db->info.device = device;
+    *out = db;
+    return KID_OK;
+}
+
 extern "C" int kid_db_get_info(const kid_db *db, kid_db_info *out)
 {
     if (!db || !out) return kid_fail(KID_ERR_ARG, "null argument");
@@ -1119,6 +1172,47 @@ extern "C" int kid_sample_end(kid_sample *s, int64_t *gcount, int64_t *ucount)
     int rc = kid_sample_gcount(s, gcount);
     if (rc != KID_OK) return rc;
     return kid_sample_ucount_range(s, 0, s->seen_words * 32, ucount);
+}
+
+// The counters of ONE sample of the input whose batches were dealt out over n kid_sample objects -- one per GPU, each
+// on its own replica of the database (kid_db_replicate, or kid_db_build from the same entries).  gcount adds; ucount is
+// |distinct DB k-mers hit|: the seen-bitmaps (one bit per DB entry, the same numbering on every replica) are copied
+// peer to peer into samples[0]'s GPU, OR-ed there and counted once.  This is the merge of the reference's globals
+// (newkmer_10nx.cpp:61-64) over the shards; the process-per-GPU form of it over RCCL is kmer_id_amd/dist.py.
+// samples[0]'s bitmap holds the union afterwards.
+extern "C" int kid_sample_end_merged(kid_sample **samples, int n, int64_t *gcount, int64_t *ucount)
+{
+    if (!samples || n < 1 || !gcount || !ucount) return kid_fail(KID_ERR_ARG, "bad argument");
+    for (int i = 0; i < n; i++) {
+        if (!samples[i]) return kid_fail(KID_ERR_ARG, "samples[%d] is null", i);
+        if (samples[i]->seen_words != samples[0]->seen_words || samples[i]->db->info.ntar != samples[0]->db->info.ntar ||
+            samples[i]->db->info.n_entries != samples[0]->db->info.n_entries)
+            return kid_fail(KID_ERR_ARG, "samples[%d] belongs to a database built from other entries", i);
+    }
+    kid_sample *s0 = samples[0];
+    const size_t nt = (size_t)s0->db->info.ntar;
+    int rc = kid_sample_gcount(s0, gcount);
+    if (rc != KID_OK) return rc;
+    if (n > 1) {
+        std::vector<int64_t> g(nt);
+        KidDevBuf tmp;
+        rc = kid_use_device(s0->db->device);
+        if (rc != KID_OK) return rc;
+        const size_t nbytes = (size_t)s0->seen_words * 4;
+        KID_HIP(tmp.alloc(nbytes));
+        for (int i = 1; i < n; i++) {
+            rc = kid_sample_gcount(samples[i], g.data()); // (synchronises samples[i]'s device)
+            if (rc != KID_OK) return rc;
+            for (size_t t = 0; t < nt; t++) gcount[t] += g[t];
+            rc = kid_use_device(s0->db->device);
+            if (rc != KID_OK) return rc;
+            if (samples[i]->db->device == s0->db->device) KID_HIP(hipMemcpy(tmp.p, samples[i]->seen, nbytes, hipMemcpyDeviceToDevice));
+            else KID_HIP(hipMemcpyPeer(tmp.p, s0->db->device, samples[i]->seen, samples[i]->db->device, nbytes));
+            rc = kid_sample_seen_or(s0, 0, nbytes, tmp.p, 1);
+            if (rc != KID_OK) return rc;
+        }
+    }
+    return kid_sample_ucount_range(s0, 0, s0->seen_words * 32, ucount);
 }
 
 extern "C" int kid_sample_stats(kid_sample *s, uint64_t out[4])

@@ -32,8 +32,30 @@ void load_database(const std::string &tree_path, const std::string &probes_path,
 
 Engine::~Engine()
 {
-    if (sample) kid_sample_destroy(sample);
-    if (db) kid_db_destroy(db);
+    for (kid_sample *s : samples) kid_sample_destroy(s);
+    for (kid_db *d : dbs) kid_db_destroy(d);
+}
+
+std::vector<int> parse_devices(const std::string &list)
+{
+    std::vector<int> out;
+    size_t pos = 0;
+    while (pos <= list.size()) {
+        size_t comma = list.find(',', pos);
+        if (comma == std::string::npos) comma = list.size();
+        if (comma > pos) out.push_back(atoi(list.substr(pos, comma - pos).c_str()));
+        pos = comma + 1;
+    }
+    return out;
+}
+
+void engine_reset(Engine &e)
+{
+    for (kid_sample *s : e.samples) {
+        int rc = kid_sample_reset(s);
+        if (rc != KID_OK) die_kid(rc);
+    }
+    e.next_sample = 0;
 }
 
 bool engine_open(Engine &e, const ProbeSet &ps, const std::vector<int32_t> &parent, int k, int log2_slots, int max_probes,
@@ -47,6 +69,26 @@ bool engine_open(Engine &e, const ProbeSet &ps, const std::vector<int32_t> &pare
     if (rc != KID_OK) die_kid(rc);
     rc = kid_sample_begin(e.db, &e.sample);
     if (rc != KID_OK) die_kid(rc);
+    e.dbs.assign(1, e.db);
+    e.samples.assign(1, e.sample);
+    return true;
+}
+
+bool engine_open(Engine &e, const ProbeSet &ps, const std::vector<int32_t> &parent, int k, int log2_slots, int max_probes,
+                 unsigned flags, const std::vector<int> &devices)
+{
+    if (devices.empty()) { std::cerr << "kmer_id_amd: no device given\n"; exit(2); }
+    if (!engine_open(e, ps, parent, k, log2_slots, max_probes, flags, devices[0])) return false;
+    for (size_t i = 1; i < devices.size(); i++) { // the reference, pinned into every GPU's HBM: device-to-device copies of the one built table
+        kid_db *r = nullptr;
+        int rc = kid_db_replicate(e.db, devices[i], &r);
+        if (rc != KID_OK) die_kid(rc);
+        e.dbs.push_back(r);
+        kid_sample *s = nullptr;
+        rc = kid_sample_begin(r, &s);
+        if (rc != KID_OK) die_kid(rc);
+        e.samples.push_back(s);
+    }
     return true;
 }
 
@@ -146,12 +188,14 @@ long long run_file(Engine &e, Prefetcher &pf, size_t index, ReadSaver &saver)
         std::unique_ptr<ReadBatch> batch;
         std::vector<uint32_t> final_targ;
         uint64_t ticket = 0;
+        kid_sample *sample = nullptr;
     };
     std::deque<InFlight> q;
     long long n = 0;
+    const size_t max_in_flight = 2 * e.samples.size();
     auto retire = [&]() {
         InFlight &f = q.front();
-        int rc = kid_classify_wait(e.sample, f.ticket);
+        int rc = kid_classify_wait(f.sample, f.ticket);
         if (rc != KID_OK) die_kid(rc);
         saver.add_batch(*f.batch, f.final_targ);
         q.pop_front();
@@ -161,11 +205,13 @@ long long run_file(Engine &e, Prefetcher &pf, size_t index, ReadSaver &saver)
         InFlight &f = q.back();
         f.batch = std::move(b);
         f.final_targ.resize(f.batch->size());
-        int rc = kid_classify_batch_async(e.sample, f.batch->bases.data(), f.batch->offsets.data(), f.batch->start.data(),
+        f.sample = e.samples[e.next_sample]; // batches are dealt round-robin over the devices
+        e.next_sample = (e.next_sample + 1) % e.samples.size();
+        int rc = kid_classify_batch_async(f.sample, f.batch->bases.data(), f.batch->offsets.data(), f.batch->start.data(),
                                           f.batch->stop.data(), f.batch->size(), f.final_targ.data(), &f.ticket);
         if (rc != KID_OK) die_kid(rc);
         n += (long long)f.batch->size();
-        while (q.size() > 2) retire();
+        while (q.size() > max_in_flight) retire();
     }
     while (!q.empty()) retire();
     return n;
@@ -196,7 +242,8 @@ void dry_dump_source(FILE *f, const std::string &label, ReadSource &src, size_t 
 void finish_sample(Engine &e, const std::string &result_path)
 {
     std::vector<int64_t> g((size_t)e.ntar), u((size_t)e.ntar);
-    int rc = kid_sample_end(e.sample, g.data(), u.data());
+    int rc = e.samples.size() > 1 ? kid_sample_end_merged(e.samples.data(), (int)e.samples.size(), g.data(), u.data())
+                                  : kid_sample_end(e.sample, g.data(), u.data());
     if (rc != KID_OK) die_kid(rc);
     write_result(result_path, g, u);
 }

@@ -12,8 +12,14 @@
 namespace kidhost {
 
 struct Engine {
-    kid_db *db = nullptr;
-    kid_sample *sample = nullptr;
+    kid_db *db = nullptr;         // the database on the first device
+    kid_sample *sample = nullptr; // ... and its sample
+    // one replica of the database + one sample per device (--devices a,b,...): [0] are the two above.  The batches of
+    // a file are dealt round-robin over the samples, the per-read results come back in file order, and closing a
+    // sample merges the replicas' counters (kid_sample_end_merged).
+    std::vector<kid_db *> dbs;
+    std::vector<kid_sample *> samples;
+    size_t next_sample = 0;
     int ntar = 0, k = 30;
     size_t batch_reads = 1 << 20;
     size_t batch_bases = 256u << 20;
@@ -31,6 +37,12 @@ void load_database(const std::string &tree_path, const std::string &probes_path,
 // and exits with 1 (newkmer_10nx.cpp:256-260).
 bool engine_open(Engine &e, const ProbeSet &ps, const std::vector<int32_t> &parent, int k, int log2_slots, int max_probes,
                  unsigned flags, int device);
+// the same on several devices ("0,1,2,3"; a device may be named twice): the table is built once and replicated
+bool engine_open(Engine &e, const ProbeSet &ps, const std::vector<int32_t> &parent, int k, int log2_slots, int max_probes,
+                 unsigned flags, const std::vector<int> &devices);
+std::vector<int> parse_devices(const std::string &list);
+// newkmer_10nx.cpp:1017-1019 on every replica
+void engine_reset(Engine &e);
 
 // The input files of a run, parsed (+ trimmed) ahead of their turn on a small pool of reader threads:
 // gzip inflate + parsing is the slow half of the program (~1 M reads/s per core) and files are

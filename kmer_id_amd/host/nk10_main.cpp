@@ -8,6 +8,8 @@
 //
 // Options after the directory (all optional, defaults = the reference's compile-time constants):
 //   --db-dir DIR (./bact10/)  --ntar N (5982)  --k K (30)  --log2-slots L (30)  --device D (0)
+//   --devices A,B,...  several GPUs: the table is built on the first and replicated into the others' HBM, the batches of
+//                    a sample are dealt round-robin over them, the counters merged when the sample is closed
 //   --batch-reads N (262144)  --threads T (4: reader threads parsing files ahead)  --r1 SUFFIX (_R1_tr.fastq.gz)  --r2 SUFFIX (_R2_tr.fastq.gz)
 //   --fasta          the reference's compile-time FASTQ=0 mode (:28,:1032-1035): one plain FASTA file
 //                    <prefix><r1 suffix> per sample, read by process_fa (:877-913), no R2 file
@@ -35,7 +37,7 @@ int main(int argc, char **argv)
     std::string dname, db_dir = "./bact10/", e1 = "_R1_tr.fastq.gz", e2 = "_R2_tr.fastq.gz";
     int ntar = 5982, k = 30, log2_slots = 30, device = 0, threads = 4;
     size_t batch_reads = 1 << 18;
-    std::string dry_run, db_cache;
+    std::string dry_run, db_cache, device_list;
     bool fasta_mode = false;
     bool parse_only = false; // --parse-only: run the reader pool over the directory without a GPU and report its rate
     for (int i = 1; i < argc; i++) {
@@ -49,6 +51,7 @@ int main(int argc, char **argv)
         else if (a == "--k") k = atoi(val("--k"));
         else if (a == "--log2-slots") log2_slots = atoi(val("--log2-slots"));
         else if (a == "--device") device = atoi(val("--device"));
+        else if (a == "--devices") device_list = val("--devices");
         else if (a == "--batch-reads") batch_reads = (size_t)atoll(val("--batch-reads"));
         else if (a == "--threads") threads = atoi(val("--threads"));
         else if (a == "--r1") e1 = val("--r1");
@@ -135,7 +138,8 @@ int main(int argc, char **argv)
         }
         Engine eng;
         eng.batch_reads = batch_reads;
-        if (!engine_open(eng, ps, parent, k, log2_slots, 0, 0, device)) { // :256-260
+        const std::vector<int> devices = device_list.empty() ? std::vector<int>(1, device) : parse_devices(device_list);
+        if (!engine_open(eng, ps, parent, k, log2_slots, 0, 0, devices)) { // :256-260
             std::cout << "out of memory in table " << std::endl;
             return 1;
         }
@@ -180,8 +184,7 @@ int main(int argc, char **argv)
         size_t fi = 0;
         for (size_t f = 0; f < fnames.size(); f++) { // :1015-1045
             const std::string &prefix = fnames[f];
-            int rc = kid_sample_reset(eng.sample);
-            if (rc != KID_OK) die_kid(rc);
+            engine_reset(eng);
             std::cout << prefix << std::endl;
             long long tct = 0;
             {

@@ -567,6 +567,32 @@ def test_seen_bitmaps_merge_across_independent_tables(flags_b):
         x.close()
 
 
+def test_replicas_and_merged_end(seeded):
+    """kid_db_replicate + kid_sample_end_merged: three replicas of the table (on this one GPU), the reads dealt out in
+    ragged batches over their samples, one merged result = the single-table result"""
+    parent, cum, keys, targets, odb, db = seeded
+    n, L = 15000, 150
+    bases = synth.reads(cum, parent, n, L, K, r0=31337)
+    off = synth.fixed_offsets(n, L)
+    whole = db.sample(); exp = whole.classify(bases, off)
+    g, u = whole.end()
+    reps = [db, db.replicate(0), db.replicate(0)]
+    assert reps[1].info.n_entries == db.info.n_entries and reps[1].info.geometry == db.info.geometry
+    samples = [r.sample() for r in reps]
+    cuts = [0, 1, 1000, 1001, 5000, 9999, 12000, n]
+    got = np.empty(n, np.uint32)
+    for j in range(len(cuts) - 1):
+        a, b = cuts[j], cuts[j + 1]
+        got[a:b] = samples[j % 3].classify(bases, off[a:b + 1])
+    assert np.array_equal(got, exp)
+    gm, um = kmer_id_amd.end_merged(samples)
+    assert np.array_equal(gm, g) and np.array_equal(um, u)
+    for s_ in samples + [whole]:
+        s_.close()
+    for r in reps[1:]:
+        r.close()
+
+
 def test_merge_sample_over_rccl_single_rank(seeded):
     """kmer_id_amd.dist.merge_sample with the collectives forced on (world size 1, backend nccl = RCCL)"""
     import os

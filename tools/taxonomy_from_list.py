@@ -7,7 +7,13 @@ parent is the previous non-blank rank of the same row; top-rank nodes hang off r
 
   python tools/taxonomy_from_list.py            # verifies the rule on mitochondria_list.txt and writes
                                                 # kmer_id_amd/data/taxonomy_fungal.npz from fung1_list_vf6.txt
-Runs only where /root/reference exists; the .npz it writes is committed.
+                                                # (runs only where /root/reference exists; the .npz is committed)
+  python tools/taxonomy_from_list.py LIST --ranks N --acc-col C --out PREFIX [--counts FILE.npy]
+        # the converter proper: writes PREFIX_data.txt ("target<TAB>accession", list order: what kmer_read_vf6.cpp
+        # :1059-1089 reads as <name>_data.txt), PREFIX_tree.txt ("parent<TAB>child" per edge: <name>_tree.txt) and
+        # PREFIX_refkey.txt (the report scripts' key, in the layout of mitochondria_refkey.txt: header, then
+        # target, name = ranks joined by '_', probe count, three simulation columns the reference's author filled
+        # in by other means (0 here), number of strains under the node; CRLF like the reference's file)
 """
 import os
 import sys
@@ -16,6 +22,59 @@ import numpy as np
 
 REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kmer_id_amd", "data")
+
+
+def derive_named(path, n_ranks, acc_col):
+    """-> parent[], [(target, accession)], names[target], strains_under[target]"""
+    ids, parent, strain_targets = {}, {1: 1}, []
+    names = {0: "none", 1: "root"}
+    under = {}
+    nxt = 2
+    with open(path, encoding="latin-1") as fh:
+        next(fh)
+        for line in fh:
+            f = line.rstrip("\r\n").split("\t")
+            if len(f) <= acc_col or not f[acc_col].strip():
+                continue
+            path_key, prev, lineage = (), 1, []
+            for r in range(n_ranks):
+                name = f[r].strip()
+                if not name:
+                    continue
+                path_key = path_key + (name,)
+                if path_key not in ids:
+                    ids[path_key] = nxt
+                    parent[nxt] = prev
+                    names[nxt] = "_".join(path_key)
+                    nxt += 1
+                prev = ids[path_key]
+                lineage.append(prev)
+            for t in lineage:
+                under[t] = under.get(t, 0) + 1
+            strain_targets.append((prev, f[acc_col].strip()))
+    ntar = nxt
+    par = np.ones(ntar, np.int32)
+    for k, v in parent.items():
+        par[k] = v
+    return par, strain_targets, [names[i] for i in range(ntar)], [under.get(i, 0) for i in range(ntar)]
+
+
+def write_db_files(list_path, n_ranks, acc_col, out_prefix, probe_counts=None):
+    """The three text files of a DB (minus the probes): <prefix>_data.txt, _tree.txt, _refkey.txt."""
+    par, strains, names, under = derive_named(list_path, n_ranks, acc_col)
+    with open(out_prefix + "_data.txt", "w", newline="") as fh:
+        for t, acc in strains:
+            fh.write("%d\t%s\n" % (t, acc))
+    with open(out_prefix + "_tree.txt", "w", newline="") as fh:
+        edges = sorted((int(par[c]), c) for c in range(2, par.size) if par[c] != 1)  # top-rank nodes hang off root: no line
+        for p_, c in edges:
+            fh.write("%d\t%d\n" % (p_, c))
+    with open(out_prefix + "_refkey.txt", "w", newline="") as fh:
+        fh.write("target\tname\tprobe count\treads hit\treads tested\ttotal size\tstrains\r\n")
+        for t in range(par.size):
+            pc = int(probe_counts[t]) if probe_counts is not None and t < len(probe_counts) else 0
+            fh.write("%d\t%s\t%d\t0\t0\t0\t%d\r\n" % (t, names[t], pc, under[t]))
+    return par, strains, names, under
 
 
 def derive(path, n_ranks, acc_col):
@@ -76,4 +135,16 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:
+        import argparse
+        ap = argparse.ArgumentParser()
+        ap.add_argument("list")
+        ap.add_argument("--ranks", type=int, required=True, help="number of taxonomy columns (mitochondria_list.txt: 6, fung1_list_vf6.txt: 8)")
+        ap.add_argument("--acc-col", type=int, required=True, help="0-based column of the accession (mitochondria_list.txt: 6, fung1_list_vf6.txt: 8)")
+        ap.add_argument("--out", required=True, help="output prefix")
+        ap.add_argument("--counts", help=".npy of probe counts per target for the refkey")
+        a = ap.parse_args()
+        par, strains, names, under = write_db_files(a.list, a.ranks, a.acc_col, a.out, np.load(a.counts) if a.counts else None)
+        print("%d nodes, %d strains -> %s_{data,tree,refkey}.txt" % (par.size, len(strains), a.out))
+    else:
+        main()
