@@ -259,6 +259,9 @@ def main():
     ap.add_argument("--cpu-reads", type=int, default=300_000, help="reads of the CPU baseline sample (0 = skip)")
     ap.add_argument("--batches", type=int, default=None, help="distinct resident read batches cycled over the steps")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline leg (0 = every core of this host)")
+    ap.add_argument("--overlap-pack", type=int, default=0,
+                    help="KID_OPT_INPUTS_READY: pack + prepare of the next resident batch run beside the classify kernels of this one "
+                         "(measured: same pairs/s, the classify kernel is 5-8 %% slower while pack shares the chip: profiles/r02/ab_overlap_pack.txt)")
     ap.add_argument("--host-leg", type=int, default=1, help="N = 1: also time the host-buffer (PCIe-inclusive) path")
     ap.add_argument("--e2e-leg", type=int, default=1, help="N = 1: also time the nk10 command line on FASTQ.gz files")
     ap.add_argument("--verify-ranks", type=int, default=1,
@@ -311,6 +314,9 @@ def main():
     batches = [gen_reads(device, cum, parent, (rank * nb + b) * n_reads, n_reads) for b in range(nb)]
     out_final = torch.empty(n_reads, dtype=torch.int32, device=device)
     sample = db.sample()
+    # the batches are resident in HBM and final: the library may pack batch i + 1 while batch i is being classified
+    if args.overlap_pack:
+        sample.set_option(kmer_id_amd.KID_OPT_INPUTS_READY, 1)
     stream = torch.cuda.current_stream(device)
 
     def step(i):
@@ -468,7 +474,7 @@ def main():
             "config": {"workload": "bact10-synth DB (%d 30-mers on the real bact10 taxonomy, 2^%d-cell table resident in HBM), "
                                    "%d synthetic %d bp read pairs per GPU per step, reads resident in HBM" % (
                                        info.n_entries, args.log2_slots, args.pairs, READ_LEN),
-                       "name": args.config, "db_scale": args.scale, "pairs_per_gpu_per_step": args.pairs, "read_len": READ_LEN, "k": K,
+                       "name": args.config, "inputs_ready_option": bool(args.overlap_pack), "db_scale": args.scale, "pairs_per_gpu_per_step": args.pairs, "read_len": READ_LEN, "k": K,
                        "merged_counters_equal_single_table": ranks_verified,
                        "sharding": "reads sharded over %d rank(s), DB replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -109,6 +109,12 @@ int kid_db_msca(kid_db *db, const int32_t *x, const int32_t *y, uint64_t n, int3
 /* ---- per-sample state ----------------------------------------------------
  * Replaces the per-sample reset in main (newkmer_10nx.cpp:1017-1019,1023).   */
 int kid_sample_begin(kid_db *db, kid_sample **out);
+/* options of a sample */
+#define KID_OPT_INPUTS_READY 1 /* value 1: the read text handed to kid_classify_batch_device / kid_classify_fixed_device is
+                                  final when the call is made and stays untouched until the batch is through (e.g. batches
+                                  resident in HBM): the library may then pack a batch on a stream of its own while the batch
+                                  before is still being classified, instead of strictly behind it in `stream` */
+int kid_sample_set_option(kid_sample *s, int option, int value);
 int kid_sample_reset(kid_sample *s);
 void kid_sample_destroy(kid_sample *s);
 

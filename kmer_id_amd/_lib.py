@@ -43,6 +43,7 @@ PROTOTYPES = {
     "kid_hash_keys": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]),
     "kid_db_msca": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "kid_sample_begin": (C.c_int, [C.c_void_p, c_void_pp]),
+    "kid_sample_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "kid_sample_reset": (C.c_int, [C.c_void_p]),
     "kid_sample_destroy": (None, [C.c_void_p]),
     "kid_classify_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
@@ -82,6 +83,7 @@ PROTOTYPES = {
     "kid_dev_sync": (C.c_int, [C.c_int]),
 }
 
+KID_OPT_INPUTS_READY = 1
 KID_FLAG_U_IS_T = 1
 KID_FLAG_HOST_BUILD = 2
 KID_FLAG_REF_GEOMETRY = 4

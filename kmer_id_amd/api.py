@@ -174,6 +174,9 @@ class Sample:
     def reset(self):
         check(self._lib.kid_sample_reset(self._h))
 
+    def set_option(self, option, value=1):
+        check(self._lib.kid_sample_set_option(self._h, option, value))
+
     def classify(self, bases, offsets, start=None, stop=None, want_final=True):
         """process_read for a batch held in host memory; returns final_targ per read."""
         bases = _as(bases, np.uint8)

@@ -82,19 +82,32 @@ struct kid_sample {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed; // around each classify launch, while timing is on
     uint64_t timed_batches = 0;
     // per-batch scratch of the device pipeline (prepare -> pack -> classify), grown on demand
-    KidRareArgs *d_rare = nullptr; // device copy, written once in kid_sample_begin (batch_max: by every batch)
     uint32_t *d_dyn = nullptr;     // chunk counters of the pair kernel's dynamic tail (KID_DYN_SHARDS x 64 bytes)
     uint32_t batch_seq = 0;
+    // Per-batch scratch of the device pipeline (pack -> prepare -> classify), grown on demand.  Three sets taken in
+    // turn, so that pack + prepare of batch b + 1 can run (on another stream) while the classify kernels of batch b
+    // still read theirs: the packed image, the descriptors and the device argument block the kernels find them in.
+    struct Scratch {
+        KidReadDesc *desc = nullptr;
+        uint64_t desc_cap = 0;
+        uint32_t *codes = nullptr;
+        uint16_t *inval = nullptr;
+        uint64_t chunks_cap = 0;
+        KidRareArgs *rare = nullptr;  // device copy, written in kid_sample_begin (per batch: batch_max, desc, out_final)
+        hipEvent_t ev_prep = nullptr; // pack + prepare of the batch using the set are done
+        hipEvent_t ev_used = nullptr; // ... its classify kernels are done: the set may be overwritten
+        bool used = false;
+    };
+    static const int NSET = 3;
+    Scratch sets[NSET];
+    uint32_t next_set = 0;
+    hipStream_t prep_stream = nullptr; // pack + prepare of the *_device entry points when the caller promised KID_OPT_INPUTS_READY
+    bool inputs_ready = false;
     uint64_t reads_submitted = 0; // since the last reset: checked against the device's count when results are read
     // the scratch below is one set per sample: batches on different streams are ordered behind each other
     hipStream_t last_stream = nullptr;
     bool has_last_stream = false;
     hipEvent_t order_ev = nullptr;
-    KidReadDesc *sc_desc = nullptr;
-    uint64_t sc_desc_cap = 0;
-    uint32_t *sc_codes = nullptr;
-    uint16_t *sc_inval = nullptr;
-    uint64_t sc_chunks_cap = 0;
     // Staging for the host-buffer entry points: a ring of slots so that the upload of batch b + 1 (copy stream) and
     // the download of batch b - 1's results (result stream) run beside the kernels of batch b (the sample's stream).
     struct Slot {
@@ -553,12 +566,17 @@ extern "C" void kid_sample_destroy(kid_sample *s)
     if (s->stats) hipFree(s->stats);
     if (s->seen) hipFree(s->seen);
     for (auto &ev : s->timed) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
-    if (s->d_rare) hipFree(s->d_rare);
+    for (kid_sample::Scratch &sc : s->sets) {
+        if (sc.rare) hipFree(sc.rare);
+        if (sc.desc) hipFree(sc.desc);
+        if (sc.codes) hipFree(sc.codes);
+        if (sc.inval) hipFree(sc.inval);
+        if (sc.ev_prep) hipEventDestroy(sc.ev_prep);
+        if (sc.ev_used) hipEventDestroy(sc.ev_used);
+    }
+    if (s->prep_stream) hipStreamDestroy(s->prep_stream);
     if (s->d_dyn) hipFree(s->d_dyn);
     if (s->order_ev) hipEventDestroy(s->order_ev);
-    if (s->sc_desc) hipFree(s->sc_desc);
-    if (s->sc_codes) hipFree(s->sc_codes);
-    if (s->sc_inval) hipFree(s->sc_inval);
     hipDeviceSynchronize();
     for (kid_sample::Slot &sl : s->slots) {
         if (sl.bases) hipFree(sl.bases);
@@ -624,8 +642,12 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
         KID_S_HIP(hipMalloc(&s->d_dyn, dyn_bytes));
         KID_S_HIP(hipMemset(s->d_dyn, 0, dyn_bytes));
         const KidRareArgs ra{s->gcount, s->stats, db->d.line_mask, 0u, s->d_dyn, 0ull, db->rows, s->seen, nullptr, nullptr};
-        KID_S_HIP(hipMalloc(&s->d_rare, sizeof(ra)));
-        KID_S_HIP(hipMemcpy(s->d_rare, &ra, sizeof(ra), hipMemcpyHostToDevice));
+        for (kid_sample::Scratch &sc : s->sets) {
+            KID_S_HIP(hipMalloc(&sc.rare, sizeof(ra)));
+            KID_S_HIP(hipMemcpy(sc.rare, &ra, sizeof(ra), hipMemcpyHostToDevice));
+            KID_S_HIP(hipEventCreateWithFlags(&sc.ev_prep, hipEventDisableTiming));
+            KID_S_HIP(hipEventCreateWithFlags(&sc.ev_used, hipEventDisableTiming));
+        }
     }
 #undef KID_S_HIP
     rc = kid_sample_reset(s);
@@ -641,15 +663,19 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
 // histogram lives in LDS when 4 workgroups per CU still fit).
 // max_kmers: the largest n_kmers of the batch when the host knows it (then only the kernel the batch is for is
 // launched), -1 when only the device does
-static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_nbytes, hipStream_t stream, int64_t max_kmers)
+// prep_stream: where pack + prepare run.  The same as `stream` unless the read text is known to be ready earlier
+// than stream order says (host path: the copy stream behind the upload; device entry points under
+// KID_OPT_INPUTS_READY: an internal stream) -- then they overlap with the classify kernels of the batch before.
+static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_nbytes, hipStream_t stream, int64_t max_kmers,
+                               hipStream_t prep_stream)
 {
     kid_db *db = s->db;
     if (b.n == 0) return KID_OK;
     if (b.n > 0x7FFFFFFFull) return kid_fail(KID_ERR_ARG, "at most 2^31-1 reads per batch");
     if (bases_nbytes >> 48) return kid_fail(KID_ERR_ARG, "a batch of 2^48 bytes or more");
     const uint64_t nchunks = (bases_nbytes + 15) / 16;
-    // All batches of a sample share its scratch (descriptors, packed image, the device argument block): a batch
-    // issued on another stream than the one before is made to wait for it (or for the resize below, the device).
+    // The classify kernels of a sample's batches run one after the other (they share the sample's counters' timing
+    // stamps and chunk counters): a batch issued on another stream than the one before is made to wait for it.
     if (s->has_last_stream && s->last_stream != stream) {
         if (!s->order_ev) KID_HIP(hipEventCreateWithFlags(&s->order_ev, hipEventDisableTiming));
         KID_HIP(hipEventRecord(s->order_ev, s->last_stream));
@@ -657,26 +683,33 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     }
     s->last_stream = stream;
     s->has_last_stream = true;
-    if (b.n > s->sc_desc_cap || nchunks > s->sc_chunks_cap) KID_HIP(hipDeviceSynchronize()); // (scratch in use is not freed)
-    if (b.n > s->sc_desc_cap) {
-        if (s->sc_desc) hipFree(s->sc_desc);
-        s->sc_desc = nullptr; s->sc_desc_cap = 0;
-        KID_HIP(hipMalloc(&s->sc_desc, b.n * sizeof(KidReadDesc)));
-        s->sc_desc_cap = b.n;
+    kid_sample::Scratch &sc = s->sets[s->next_set++ % kid_sample::NSET];
+    if (b.n > sc.desc_cap || nchunks > sc.chunks_cap) KID_HIP(hipDeviceSynchronize()); // (scratch in use is not freed)
+    if (b.n > sc.desc_cap) {
+        if (sc.desc) hipFree(sc.desc);
+        sc.desc = nullptr; sc.desc_cap = 0;
+        KID_HIP(hipMalloc(&sc.desc, b.n * sizeof(KidReadDesc)));
+        sc.desc_cap = b.n;
     }
-    if (nchunks > s->sc_chunks_cap) {
-        if (s->sc_codes) hipFree(s->sc_codes);
-        if (s->sc_inval) hipFree(s->sc_inval);
-        s->sc_codes = nullptr; s->sc_inval = nullptr; s->sc_chunks_cap = 0;
-        KID_HIP(hipMalloc(&s->sc_codes, (nchunks + 64) * 4));
-        KID_HIP(hipMalloc(&s->sc_inval, (nchunks + 64) * 2));
-        s->sc_chunks_cap = nchunks;
+    if (nchunks > sc.chunks_cap) {
+        if (sc.codes) hipFree(sc.codes);
+        if (sc.inval) hipFree(sc.inval);
+        sc.codes = nullptr; sc.inval = nullptr; sc.chunks_cap = 0;
+        KID_HIP(hipMalloc(&sc.codes, (nchunks + 64) * 4));
+        KID_HIP(hipMalloc(&sc.inval, (nchunks + 64) * 2));
+        sc.chunks_cap = nchunks;
     }
+    // the batch that used this set three batches ago must be through its classify kernels before the set is overwritten
+    if (sc.used) KID_HIP(hipStreamWaitEvent(prep_stream, sc.ev_used, 0));
     if (nchunks)
-        hipLaunchKernelGGL(kid_pack_kernel, dim3(kid_grid_for(nchunks, 256, db->num_cu * 16)), dim3(256), 0, stream, b.bases,
-                           nchunks, db->d.u_is_t, s->sc_codes, s->sc_inval);
-    hipLaunchKernelGGL(kid_prepare_kernel, dim3(kid_grid_for(b.n, 256, db->num_cu * 8)), dim3(256), 0, stream, b, db->info.k,
-                       s->sc_desc, s->stats, s->d_rare, ++s->batch_seq, nchunks ? s->sc_inval : nullptr);
+        hipLaunchKernelGGL(kid_pack_kernel, dim3(kid_grid_for(nchunks, 256, db->num_cu * 16)), dim3(256), 0, prep_stream, b.bases,
+                           nchunks, db->d.u_is_t, sc.codes, sc.inval);
+    hipLaunchKernelGGL(kid_prepare_kernel, dim3(kid_grid_for(b.n, 256, db->num_cu * 8)), dim3(256), 0, prep_stream, b, db->info.k,
+                       sc.desc, s->stats, sc.rare, ++s->batch_seq, nchunks ? sc.inval : nullptr);
+    if (prep_stream != stream) {
+        KID_HIP(hipEventRecord(sc.ev_prep, prep_stream));
+        KID_HIP(hipStreamWaitEvent(stream, sc.ev_prep, 0));
+    }
     const int block = 512, wpb = block / 64;
     const uint32_t ntar = (uint32_t)db->info.ntar;
     // the gcount histogram lives in LDS while four workgroups per CU (160 KiB) still fit beside the waves' strips
@@ -709,14 +742,15 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     }
     for (uint64_t r0 = 0; r0 < b.n; r0 += span) {
     const uint64_t cnt = b.n - r0 < span ? b.n - r0 : span;
-    KidPacked pk{s->sc_codes, s->sc_inval, s->sc_desc + r0, b.out_final ? b.out_final + r0 : nullptr, cnt};
-    if (r0 != 0) // the kernels find this launch's descriptors and result array in the sample's device struct
-        hipLaunchKernelGGL(kid_rebase_kernel, dim3(1), dim3(64), 0, stream, s->d_rare, pk.desc, pk.out_final);
+    KidPacked pk{sc.codes, sc.inval, sc.desc + r0, b.out_final ? b.out_final + r0 : nullptr, cnt};
+    // the kernels find this launch's descriptors and result array in the set's device argument block; the first launch
+    // of a batch also banks / arms the device-clock stamps (here, in classify-stream order: prepare may run early)
+    hipLaunchKernelGGL(kid_rebase_kernel, dim3(1), dim3(64), 0, stream, sc.rare, pk.desc, pk.out_final, s->stats, r0 == 0 ? 1 : 0);
 #define KID_LAUNCH1(R, H, M, KF, PK)                                                                                            \
     hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, KF, PK>), dim3(grid), dim3(block),                                     \
                        (((H) ? ((PK) ? hist_words16 : hist_words) : 0u) +                                                       \
                         (size_t)wpb * ((PK) ? KID_PAIR_LDS_WORDS : wave_words)) * 4 + 32, stream,                              \
-                       db->d, pk, sd, (H) ? ((PK) ? hist_words16 : hist_words) : 0u, pk.desc, s->d_rare)
+                       db->d, pk, sd, (H) ? ((PK) ? hist_words16 : hist_words) : 0u, pk.desc, sc.rare)
 #define KID_LAUNCH(R, H, M)                                                                                                    \
     do {                                                                                                                       \
         if (db->info.k == 30) KID_LAUNCH1(R, H, M, 30, 0);                                                                     \
@@ -762,8 +796,29 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
         s->timed.emplace_back(ev0.release(), ev1.release());
         s->timed_batches++;
     }
+    KID_HIP(hipEventRecord(sc.ev_used, stream));
+    sc.used = true;
     KID_HIP(hipGetLastError());
     s->reads_submitted += b.n;
+    return KID_OK;
+}
+
+extern "C" int kid_sample_set_option(kid_sample *s, int option, int value)
+{
+    if (!s) return kid_fail(KID_ERR_ARG, "null sample");
+    switch (option) {
+    case KID_OPT_INPUTS_READY: s->inputs_ready = value != 0; return KID_OK;
+    default: return kid_fail(KID_ERR_ARG, "unknown option %d", option);
+    }
+}
+
+// pack + prepare stream of the *_device entry points
+static int kid_prep_stream_for(kid_sample *s, hipStream_t stream, hipStream_t *out)
+{
+    *out = stream;
+    if (!s->inputs_ready) return KID_OK;
+    if (!s->prep_stream) KID_HIP(hipStreamCreateWithFlags(&s->prep_stream, hipStreamNonBlocking));
+    *out = s->prep_stream;
     return KID_OK;
 }
 
@@ -830,7 +885,10 @@ extern "C" int kid_classify_batch_device(kid_sample *s, const void *d_bases, uin
     b.out_final = (uint32_t *)d_out_final_targ;
     b.n = n_reads;
     b.fixed_len = 0;
-    return kid_launch_classify(s, b, bases_nbytes, (hipStream_t)stream, -1);
+    hipStream_t prep;
+    rc = kid_prep_stream_for(s, (hipStream_t)stream, &prep);
+    if (rc != KID_OK) return rc;
+    return kid_launch_classify(s, b, bases_nbytes, (hipStream_t)stream, -1, prep);
 }
 
 extern "C" int kid_classify_fixed_device(kid_sample *s, const void *d_bases, uint32_t read_len, uint64_t n_reads,
@@ -847,7 +905,10 @@ extern "C" int kid_classify_fixed_device(kid_sample *s, const void *d_bases, uin
     b.n = n_reads;
     b.fixed_len = read_len;
     const int64_t nk = (int64_t)read_len - s->db->info.k + 1;
-    return kid_launch_classify(s, b, n_reads * (uint64_t)read_len, (hipStream_t)stream, nk > 0 ? nk : 0);
+    hipStream_t prep;
+    rc = kid_prep_stream_for(s, (hipStream_t)stream, &prep);
+    if (rc != KID_OK) return rc;
+    return kid_launch_classify(s, b, n_reads * (uint64_t)read_len, (hipStream_t)stream, nk > 0 ? nk : 0, prep);
 }
 
 // ---- host buffers: asynchronous slot pipeline -------------------------------------------------------------------
@@ -896,10 +957,11 @@ static int kid_slot_acquire(kid_sample *s, uint64_t n_reads, uint64_t nbytes, bo
 static int kid_slot_submit(kid_sample *s, kid_sample::Slot &sl, const KidBatch &b, uint64_t nbytes, int64_t max_kmers,
                            uint32_t *out_final_targ, uint64_t *ticket)
 {
+    // pack + prepare follow the upload on the copy stream (beside the classify kernels of the batch before); the
+    // classify kernels wait for them on the sample's stream
     KID_HIP(hipEventRecord(sl.ev_h2d, s->copy_stream));
-    KID_HIP(hipStreamWaitEvent(s->stream, sl.ev_h2d, 0));
     static const bool dbg_no_kernels = getenv("KID_DEBUG_NO_KERNELS") != nullptr; // timing experiments only
-    int rc = dbg_no_kernels ? KID_OK : kid_launch_classify(s, b, nbytes, s->stream, max_kmers);
+    int rc = dbg_no_kernels ? KID_OK : kid_launch_classify(s, b, nbytes, s->stream, max_kmers, s->copy_stream);
     if (rc != KID_OK) return rc;
     KID_HIP(hipEventRecord(sl.ev_done, s->stream));
     if (out_final_targ) {
