@@ -446,4 +446,47 @@ void ReadSaver::add_batch(const ReadBatch &b, const std::vector<uint32_t> &final
     }
 }
 
+// ---------------------------------------------------------------- job lists (kmer_read_vf6.cpp:1021-1057)
+namespace {
+struct TextLines { // getline with one trailing '\r' removed, like the reference does by hand
+    std::ifstream in;
+    explicit TextLines(const std::string &path) : in(path) {}
+    bool next(std::string &line)
+    {
+        if (!std::getline(in, line)) return false;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        return true;
+    }
+};
+} // namespace
+
+bool load_job_list(const std::string &path, JobList &out)
+{
+    out = JobList();
+    TextLines text(path);
+    if (!text.in) return false;
+    std::string line, token; // `token` survives from line to line: an empty file line repeats the previous name
+    while (text.next(line)) {
+        if (line.length() <= 1) continue;
+        int declared = 0;
+        {
+            std::stringstream fields(line);
+            fields >> token >> declared;
+        }
+        out.header_name.push_back(token);
+        out.header_count.push_back(declared);
+        out.file_rows.emplace_back();
+        std::vector<std::string> &row = out.file_rows[(size_t)out.runnable]; // (see JobList: not necessarily the row just added)
+        for (int i = 0; i < declared; i++) {
+            line.clear();
+            text.next(line); // (past the end of the file: an empty line, the previous name again)
+            std::stringstream fields(line);
+            fields >> token;
+            row.push_back(token);
+        }
+        if (declared > 0) out.runnable++;
+    }
+    return true;
+}
+
 } // namespace kidhost

@@ -127,6 +127,29 @@ private:
     std::string lseq_, seq_, acc_;
 };
 
+// ---------------------------------------------------------------- job lists (kmer_read_vf6)
+// <jname>/<jname>.txt: a header line "<job> <n>" followed by n lines naming input files, repeated
+// (kmer_read_vf6.cpp:1021-1057).  Read with the reference's extraction rules: lines of at most one character
+// are skipped where a header is expected, only the first blank-delimited token of a file line counts, a token
+// that is missing leaves the previous one in place, a count that does not parse reads as 0.  The reference
+// appends a header for every job line but files a job's inputs under the number of jobs THAT HAD FILES so
+// far, so headers and file rows drift apart behind a job without files; runnable jobs are the first
+// `runnable` headers with the first `runnable` file rows -- kept as is (its outputs are what we reproduce).
+struct JobList {
+    std::vector<std::string> header_name;
+    std::vector<int> header_count;
+    std::vector<std::vector<std::string>> file_rows;
+    int runnable = 0;
+    // inputs of runnable job j, as the reference walks them (:1116-1164)
+    int n_inputs(int j) const
+    {
+        const int declared = header_count[(size_t)j], have = (int)file_rows[(size_t)j].size();
+        return declared < have ? declared : have;
+    }
+};
+// false: the file is missing (the reference prints "narin <file>" and goes on without jobs)
+bool load_job_list(const std::string &path, JobList &out);
+
 // ---------------------------------------------------------------- outputs
 // <prefix>_result.txt: "i,gcount[i],ucount[i]\n" for every target (newkmer_10nx.cpp:1040-1043)
 void write_result(const std::string &path, const std::vector<int64_t> &gcount, const std::vector<int64_t> &ucount);

@@ -39,6 +39,7 @@ int main(int argc, char **argv)
 {
     std::string wdir, r1name, r2name;
     int k = 30, log2_slots = 30, device = 0, threads = 2;
+    std::string device_list;
     size_t batch_reads = 1 << 18;
     std::string dry_run; // --dry-run FILE: host stages only (no GPU), for the CPU test-suite
     std::string db_cache; // --db-cache FILE: binary cache of the parsed database
@@ -51,6 +52,7 @@ int main(int argc, char **argv)
         if (a == "--k") k = atoi(v);
         if (a == "--log2-slots") log2_slots = atoi(v);
         if (a == "--device") device = atoi(v);
+        if (a == "--devices") device_list = v; // several GPUs: replicas of the table, batches dealt round-robin, counters merged
         if (a == "--batch-reads") batch_reads = (size_t)atoll(v);
         if (a == "--dry-run") dry_run = v;
         if (a == "--threads") threads = atoi(v);
@@ -108,7 +110,8 @@ int main(int argc, char **argv)
         }
         Engine eng;
         eng.batch_reads = batch_reads;
-        if (!engine_open(eng, ps, parent, k, log2_slots, /*MAXREPROBE*/ 16, 0, device)) {
+        const std::vector<int> devices = device_list.empty() ? std::vector<int>(1, device) : parse_devices(device_list);
+        if (!engine_open(eng, ps, parent, k, log2_slots, /*MAXREPROBE*/ 16, 0, devices)) {
             std::cout << "out of memory in table " << std::endl;
             return 1;
         }

@@ -41,6 +41,7 @@ int main(int argc, char **argv)
 {
     std::string dname, wdir, jname, jdir, fdir;
     int save_target = 0, k = 30, log2_slots = 30, device = 0, threads = 4;
+    std::string device_list;
     size_t batch_reads = 1 << 18;
     std::string dry_run; // --dry-run FILE: host stages only (no GPU), for the CPU test-suite
     std::string db_cache; // --db-cache FILE: binary cache of the parsed database
@@ -54,6 +55,7 @@ int main(int argc, char **argv)
         if (a == "--k") k = atoi(v);
         if (a == "--log2-slots") log2_slots = atoi(v);
         if (a == "--device") device = atoi(v);
+        if (a == "--devices") device_list = v; // several GPUs: replicas of the table, batches dealt round-robin, counters merged
         if (a == "--batch-reads") batch_reads = (size_t)atoll(v);
         if (a == "--dry-run") dry_run = v;
         if (a == "--threads") threads = atoi(v);
@@ -62,39 +64,10 @@ int main(int argc, char **argv)
     const std::string iname = wdir + dname + "_data.txt", tname = wdir + dname + "_tree.txt",
                       pname = wdir + dname + "_probes.txt.gz", jfile = jdir + jname + ".txt";
     try {
-        // ---- job list (:1021-1057), with the reference's own extraction semantics
-        std::vector<std::vector<std::string>> fnames;
-        std::vector<std::string> jnames;
-        std::vector<int> jcounts;
-        int num_jobs = 0;
-        {
-            std::ifstream fin(jfile);
-            if (fin) {
-                std::string line, jstr;
-                int j = 0;
-                while (std::getline(fin, line)) {
-                    if (!line.empty() && line.back() == '\r') line.pop_back();
-                    if (line.length() > 1) {
-                        std::stringstream ls(line);
-                        ls >> jstr >> j;
-                        jnames.push_back(jstr);
-                        jcounts.push_back(j);
-                        fnames.push_back(std::vector<std::string>());
-                        for (int i = 0; i < j; i++) {
-                            std::getline(fin, line);
-                            if (!line.empty() && line.back() == '\r') line.pop_back();
-                            std::stringstream ls2(line);
-                            ls2 >> jstr;
-                            fnames[(size_t)num_jobs].push_back(jstr);
-                        }
-                        if (j > 0) num_jobs++;
-                    }
-                }
-                std::cout << num_jobs << " jobs" << std::endl;
-            } else {
-                std::cout << "narin " << jfile << std::endl;
-            }
-        }
+        // ---- job list (:1021-1057)
+        JobList jobs;
+        if (load_job_list(jfile, jobs)) std::cout << jobs.runnable << " jobs" << std::endl;
+        else std::cout << "narin " << jfile << std::endl;
         // ---- strain list: number of targets = largest target id + 1 (:1059-1089)
         int num_targ = 0, num_orgs = 0;
         {
@@ -129,17 +102,19 @@ int main(int argc, char **argv)
             FILE *f = fopen(dry_run.c_str(), "w");
             if (!f) { perror("kmer_read_vf6"); return 2; }
             dry_dump_db(f, parent, ps);
-            for (int j = 0; j < num_jobs; j++)
-                for (int i = 0; i < jcounts[(size_t)j] && i < (int)fnames[(size_t)j].size(); i++) {
-                    std::unique_ptr<ReadSource> src = open_by_suffix(fnames[(size_t)j][(size_t)i], k, nullptr);
-                    if (src) dry_dump_source(f, jnames[(size_t)j] + " " + fnames[(size_t)j][(size_t)i], *src, batch_reads);
+            for (int j = 0; j < jobs.runnable; j++)
+                for (int i = 0; i < jobs.n_inputs(j); i++) {
+                    const std::string &input = jobs.file_rows[(size_t)j][(size_t)i];
+                    std::unique_ptr<ReadSource> src = open_by_suffix(input, k, nullptr);
+                    if (src) dry_dump_source(f, jobs.header_name[(size_t)j] + " " + input, *src, batch_reads);
                 }
             fclose(f);
             return 0;
         }
         Engine eng;
         eng.batch_reads = batch_reads;
-        if (!engine_open(eng, ps, parent, k, log2_slots, 0, KID_FLAG_U_IS_T, device)) {
+        const std::vector<int> devices = device_list.empty() ? std::vector<int>(1, device) : parse_devices(device_list);
+        if (!engine_open(eng, ps, parent, k, log2_slots, 0, KID_FLAG_U_IS_T, devices)) {
             std::cout << "out of memory in table " << std::endl;
             return 1;
         }
@@ -147,8 +122,8 @@ int main(int argc, char **argv)
 
         std::vector<SourceOpener> files;
         std::vector<std::string> names;
-        for (int j = 0; j < num_jobs; j++)
-            for (int i = 0; i < jcounts[(size_t)j] && i < (int)fnames[(size_t)j].size(); i++) names.push_back(fnames[(size_t)j][(size_t)i]);
+        for (int j = 0; j < jobs.runnable; j++)
+            for (int i = 0; i < jobs.n_inputs(j); i++) names.push_back(jobs.file_rows[(size_t)j][(size_t)i]);
         std::vector<char> missing(names.size(), 0);
         for (size_t f = 0; f < names.size(); f++) {
             const std::string name = names[f];
@@ -162,16 +137,15 @@ int main(int argc, char **argv)
         }
         Prefetcher pf(std::move(files), threads, eng.batch_reads, eng.batch_bases);
         size_t fi = 0;
-        for (int j = 0; j < num_jobs; j++) { // :1116-1164
-            const std::string jstr = jnames[(size_t)j];
-            int rc = kid_sample_reset(eng.sample);
-            if (rc != KID_OK) die_kid(rc);
+        for (int j = 0; j < jobs.runnable; j++) { // :1116-1164
+            const std::string jstr = jobs.header_name[(size_t)j];
+            engine_reset(eng);
             const std::string base = "./" + jname + "/" + jstr;
             long long tct = 0;
             {
                 ReadSaver saver(base + "_reads.txt", num_targ, save_target > 0 ? base + "_target_reads.txt" : "",
                                 (uint32_t)(save_target > 0 ? save_target : 0), save_target == 0);
-                for (int i = 0; i < jcounts[(size_t)j] && i < (int)fnames[(size_t)j].size(); i++, fi++) {
+                for (int i = 0; i < jobs.n_inputs(j); i++, fi++) {
                     std::cout << names[fi] << std::endl;
                     tct += run_file(eng, pf, fi, saver);
                     if (missing[fi]) std::cout << "nark " << names[fi] << std::endl;

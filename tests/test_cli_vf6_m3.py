@@ -113,11 +113,13 @@ def test_vf6_host_stages_and_oracle_reproduce_the_reference(bins, tmp_path, mode
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["plain", "target"])
-def test_vf6_end_to_end(bins, tmp_path, mode):
+@pytest.mark.parametrize("mode,devices", [("plain", None), ("target", None), ("plain", "0,0"), ("target", "0,0,0")])
+def test_vf6_end_to_end(bins, tmp_path, mode, devices):
     cwd = str(tmp_path)
     src, params = setup_vf6(cwd)
     extra = ["-target", str(params["target"])] if mode == "target" else []
+    if devices:  # several replicas of the table (on this one GPU), batches dealt round-robin, counters merged
+        extra += ["--devices", devices]
     r = subprocess.run([bins["kmer_read_vf6"], "-name", "DB", "-jname", "J"] + extra + ["--log2-slots", "22", "--batch-reads", "37"],
                        cwd=cwd, check=True, stdout=subprocess.PIPE)
     assert r.stdout.decode() == open(os.path.join(src, mode, "stdout.txt")).read()
@@ -177,12 +179,14 @@ def test_m3_host_stages_and_oracle_reproduce_the_reference(bins, tmp_path):
 
 
 @pytest.mark.gpu
-def test_m3_end_to_end(bins, tmp_path):
+@pytest.mark.parametrize("devices", [None, "0,0"])
+def test_m3_end_to_end(bins, tmp_path, devices):
     cwd = str(tmp_path)
     src, params, wd = setup_m3(cwd)
     for tag, (f1, f2) in params["runs"].items():
         r = subprocess.run([bins["kmer_read_m3"], "-wdir", wd, "-f1", wd + f1, "-f2", (wd + f2) if f2 != "none" else "none",
-                            "--log2-slots", str(params["log2_slots"]), "--batch-reads", "53"], cwd=cwd, check=True, stdout=subprocess.PIPE)
+                            "--log2-slots", str(params["log2_slots"]), "--batch-reads", "53"] + (["--devices", devices] if devices else []),
+                           cwd=cwd, check=True, stdout=subprocess.PIPE)
         got = r.stdout.decode().replace(wd, "<WD>").splitlines()
         exp = open(os.path.join(src, tag + "_stdout.txt")).read().splitlines()
         # line 6 is "<length of the -f1 path> : <its last character>": the path differs, the character does not
