@@ -83,9 +83,16 @@ KID_HD int kid_base_code(uint8_t c, bool u_is_t)
 // bact10 scale, so full lines are a 1e-5 event (with 15-mers ~3 % of the lookups met one).
 // Only legal where the probe loop is unbounded (newkmer_10nx, kmer_read_vf6): there the answer
 // depends on the key -> first target map alone, not on where cells sit.
-// minimizer length m and window w = k - m + 1 (m-mers per k-mer): w = 15 (16 for k = 31), the
-// two window sizes the 16-lane row scans of the kernel support; k = 30 -> m = 16 (32 bits)
-KID_HD int kid_min_window(int k) { return k >= 31 ? 16 : 15; }
+// minimizer length m and window w = k - m + 1 (m-mers per k-mer): w <= 17 is what the 16-lane row
+// scans of the kernel support (a window may touch two rows, not three); k = 30 -> w = 17, m = 14 (28 bits)
+// w = 17 (k >= 26; k = 30 -> m = 14) also fits the two-row scheme and a read would meet 11 % fewer distinct minimizers --
+// but a k-mer's minimizer is the SMALLEST of its m-mer hashes, so the minimizers in use crowd into the lowest ~1/w of the
+// hash space: at m = 14 that leaves ~13 M lines' worth of minimizers for 108.6 M keys, the lines overflow (1.24 cells
+// per lookup instead of 1.01) and the kernel takes twice as long (profiles/r02/ab_min_window.txt).  m stays 16.
+#ifndef KID_MIN_W
+#define KID_MIN_W 15
+#endif
+KID_HD int kid_min_window(int k) { return (KID_MIN_W == 17 && k >= 26) ? 17 : (k >= 31 ? 16 : 15); }
 KID_HD int kid_min_mlen(int k) { return k - kid_min_window(k) + 1; }
 #define KID_LINE_CELLS 8    // header + 7 entries
 #define KID_LINE_ENTRIES 7

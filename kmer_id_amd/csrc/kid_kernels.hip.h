@@ -478,7 +478,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
     __syncthreads();
 
     const int k = KFIX ? KFIX : db.k; // KFIX = 30: the reference's KSIZE folded into the shifts and masks
-    const uint32_t win = (uint32_t)kid_min_window(k); // m-mers per k-mer window: 15 or 16
+    const uint32_t win = (uint32_t)kid_min_window(k); // m-mers per k-mer window: 15, 16 or 17
     const int mlen = kid_min_mlen(k);
     // lane classes of the sliding minimum.  With q = lane mod 16 the window of a lane leaves its 16-lane
     // row iff q + win > 16: then it is min(S[p], P[p+win-1]); inside one row it is the prefix P[p+win-1]
