@@ -1188,7 +1188,11 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         auto issue_header = [&](const KidGroup<U> &g, const int u) -> kid_u4 {
             const uint4 *const p = db.table + (g.act[u] ? g.hlo[u] * KID_LINE_CELLS : 0u);
             kid_u4 v;
+#ifdef KID_HDR_NT // experiment: non-temporal header loads (the random-line ceiling is 54 instead of 48.5 G lines/s with them)
+            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(v) : "v"(p) : "memory");
+#else
             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
+#endif
             return v;
         };
         uint32_t cA, iA, cB, iB;

@@ -18,22 +18,32 @@ import torch.distributed as dist
 
 
 def merge_counts(gcount, seen, count_slice, group=None, force_collectives=False):
-    """gcount: int64[ntar] tensor; seen: uint8[nbytes] tensor (this rank's bitmap), both on the
-    backend's device.  count_slice(byte_begin, byte_end, merged_slice_uint8) -> int64[ntar]
-    tensor with the ucount contribution of that slice of table cells.
+    """gcount: int64[ntar] tensor; seen: uint8[nbytes] tensor (this rank's bitmap, nbytes a multiple of 16), both on the
+    backend's device.  count_slice(byte_begin, byte_end, merged_slice_uint8) -> int64[ntar] tensor with the ucount
+    contribution of that byte range of the bitmap (byte_end <= nbytes; an empty range is never asked for).
     Returns (gcount_total, ucount_total), identical on every rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     nbytes = seen.numel()
     if world == 1 and not force_collectives:
         return gcount.clone(), count_slice(0, nbytes, seen)
-    if nbytes % (world * 16) != 0:
-        raise ValueError("bitmap of %d bytes does not split into %d 16-byte aligned slices" % (nbytes, world))
-    sl = nbytes // world
-    recv = torch.empty_like(seen)
-    dist.all_to_all_single(recv, seen, group=group)  # chunk j of recv = slice `rank` of rank j's bitmap
+    if nbytes % 16 != 0:
+        raise ValueError("bitmap of %d bytes is not a whole number of 16-byte groups" % nbytes)
+    # equal slices of whole 16-byte groups; the bitmap is padded with zero bytes up to world x slice (one bit per DB
+    # entry: its size has nothing to do with the number of ranks)
+    sl = -(-(nbytes // 16) // world) * 16
+    send = seen
+    if sl * world != nbytes:
+        send = torch.zeros(sl * world, dtype=seen.dtype, device=seen.device)
+        send[:nbytes] = seen
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)  # chunk j of recv = slice `rank` of rank j's bitmap
     merged = functools.reduce(torch.bitwise_or, recv.view(world, sl).unbind(0))
-    part = count_slice(rank * sl, (rank + 1) * sl, merged.contiguous())
+    b0, b1 = min(rank * sl, nbytes), min((rank + 1) * sl, nbytes)
+    if b1 > b0:
+        part = count_slice(b0, b1, merged[:b1 - b0].contiguous())
+    else:
+        part = torch.zeros_like(gcount)
     both = torch.stack([gcount, part.to(gcount.device)])
     dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
     return both[0], both[1]
