@@ -593,6 +593,76 @@ def test_replicas_and_merged_end(seeded):
         r.close()
 
 
+def test_async_host_batches_and_pinned_buffers(seeded):
+    """kid_classify_batch_async / kid_classify_fixed_async / kid_classify_wait: more batches than staging slots in
+    flight, ragged sizes, pinned (kid_host_alloc) and pageable buffers, waits out of order and twice, an empty batch;
+    the sample must end with the counters of the same reads classified synchronously"""
+    from kmer_id_amd import PinnedBuffer
+    parent, cum, keys, targets, odb, db = seeded
+    n, L = 9000, 150
+    bases = synth.reads(cum, parent, n, L, K, r0=555)
+    off = synth.fixed_offsets(n, L)
+    ref = db.sample(); exp = ref.classify(bases, off); g, u = ref.end()
+    s = db.sample()
+    cuts = [0, 1, 700, 701, 2500, 2500, 4000, 6500, 8999, n]   # (one empty batch)
+    outs, tickets, keep = [], [], []
+    pin = PinnedBuffer(n * L)
+    pin.array[:] = bases
+    for j in range(len(cuts) - 1):
+        a, b = cuts[j], cuts[j + 1]
+        out = np.full(b - a, 0xFFFFFFFF, np.uint32)
+        src = pin.array if j % 2 == 0 else bases            # pinned and pageable callers
+        o = np.ascontiguousarray(off[a:b + 1])
+        keep.append((o, out))
+        tickets.append(s.classify_async(src, o, out=out))
+        outs.append((a, b, out))
+    assert tickets[4] == 0                                     # the empty batch
+    for t in reversed(tickets):                                # out of order; the slots of the early ones were reused long ago
+        s.wait(t)
+    s.wait(tickets[0])                                         # waiting again is harmless
+    got = np.concatenate([o for _, _, o in outs])
+    assert np.array_equal(got, exp)
+    # fixed-length form straight from pinned memory, mixed with a synchronous call on the same sample
+    out_pin = PinnedBuffer(4 * 3000)
+    t = s.classify_fixed_async(pin.ptr, L, 3000, out_pin.ptr)
+    sync_part = s.classify(bases[3000 * L:], off[3000:] - off[3000])
+    s.wait(t)
+    assert np.array_equal(out_pin.array.view(np.uint32)[:3000], exp[:3000]) and np.array_equal(sync_part, exp[3000:])
+    g2, u2 = s.end()
+    assert np.array_equal(g2, 2 * g) and np.array_equal(u2, u)   # every read twice: reads double, distinct k-mers do not
+    with pytest.raises(kmer_id_amd.KidError):
+        s.wait(10 ** 9)                                         # a ticket that was never issued
+    pin.close(); out_pin.close(); s.close(); ref.close()
+
+
+def test_inputs_ready_option_and_streams(seeded):
+    """KID_OPT_INPUTS_READY: pack + prepare of a device batch on the library's own stream; consecutive batches of one
+    sample on different caller streams are ordered by the library.  Same counters as the plain path."""
+    import torch
+    parent, cum, keys, targets, odb, db = seeded
+    n, L = 8000, 150
+    bases = synth.reads(cum, parent, n, L, K, r0=4711)
+    off = synth.fixed_offsets(n, L)
+    ref = db.sample(); exp = ref.classify(bases, off); g, u = ref.end()
+    dev = torch.device("cuda", 0)
+    d = torch.from_numpy(np.concatenate([bases, np.zeros(64, np.uint8)])).to(dev)
+    outs = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(4)]
+    streams = [torch.cuda.Stream(dev) for _ in range(2)]
+    for opt in (0, 1):
+        s = db.sample()
+        s.set_option(kmer_id_amd.KID_OPT_INPUTS_READY, opt)
+        for i in range(4):
+            s.classify_fixed_device(d.data_ptr(), L, n, d_out=outs[i].data_ptr(), stream=streams[i % 2].cuda_stream)
+        g4, u4 = s.end()
+        assert np.array_equal(g4, 4 * g) and np.array_equal(u4, u)
+        for o in outs:
+            assert np.array_equal(o.cpu().numpy().view(np.uint32), exp)
+        s.close()
+    with pytest.raises(kmer_id_amd.KidError):
+        ref.set_option(99, 1)
+    ref.close()
+
+
 def test_merge_sample_over_rccl_single_rank(seeded):
     """kmer_id_amd.dist.merge_sample with the collectives forced on (world size 1, backend nccl = RCCL)"""
     import os
