@@ -57,6 +57,13 @@ struct KidEvent {
     hipEvent_t release() { hipEvent_t r = e; e = nullptr; return r; }
 };
 
+// the long records of a host batch that go through kid_long_hits_kernel / kid_long_fold_kernel
+struct KidLongPlan {
+    std::vector<KidLongRec> recs;
+    uint64_t total_kmers = 0, n_tiles = 0;
+    uint32_t cut = 0; // reads with more k-mers than this are in `recs`
+};
+
 struct kid_db {
     int device = 0;
     int num_cu = 0;
@@ -103,6 +110,13 @@ struct kid_sample {
     uint32_t next_set = 0;
     hipStream_t prep_stream = nullptr; // pack + prepare of the *_device entry points when the caller promised KID_OPT_INPUTS_READY
     bool inputs_ready = false;
+    // very long records of host batches: their list and one word per k-mer position for the hits
+    KidLongRec *long_recs = nullptr;
+    uint64_t long_recs_cap = 0;
+    uint32_t *long_hits = nullptr;
+    uint64_t long_hits_cap = 0;
+    uint8_t *long_tiles = nullptr; // "this tile of 256 positions holds a hit"
+    uint64_t long_tiles_cap = 0;
     uint64_t reads_submitted = 0; // since the last reset: checked against the device's count when results are read
     // the scratch below is one set per sample: batches on different streams are ordered behind each other
     hipStream_t last_stream = nullptr;
@@ -119,6 +133,7 @@ struct kid_sample {
         uint64_t reads_cap = 0;
         hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_out = nullptr;
         std::vector<uint64_t> rel; // offsets rebased to the slot (alive until the copy has been issued AND done)
+        KidLongPlan plan;          // the batch's very long records
         uint64_t ticket = 0;
         bool busy = false;
     };
@@ -575,6 +590,9 @@ extern "C" void kid_sample_destroy(kid_sample *s)
         if (sc.ev_used) hipEventDestroy(sc.ev_used);
     }
     if (s->prep_stream) hipStreamDestroy(s->prep_stream);
+    if (s->long_recs) hipFree(s->long_recs);
+    if (s->long_hits) hipFree(s->long_hits);
+    if (s->long_tiles) hipFree(s->long_tiles);
     if (s->d_dyn) hipFree(s->d_dyn);
     if (s->order_ev) hipEventDestroy(s->order_ev);
     hipDeviceSynchronize();
@@ -667,7 +685,7 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
 // than stream order says (host path: the copy stream behind the upload; device entry points under
 // KID_OPT_INPUTS_READY: an internal stream) -- then they overlap with the classify kernels of the batch before.
 static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_nbytes, hipStream_t stream, int64_t max_kmers,
-                               hipStream_t prep_stream)
+                               hipStream_t prep_stream, const KidLongPlan *plan = nullptr)
 {
     kid_db *db = s->db;
     if (b.n == 0) return KID_OK;
@@ -705,7 +723,7 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
         hipLaunchKernelGGL(kid_pack_kernel, dim3(kid_grid_for(nchunks, 256, db->num_cu * 16)), dim3(256), 0, prep_stream, b.bases,
                            nchunks, db->d.u_is_t, sc.codes, sc.inval);
     hipLaunchKernelGGL(kid_prepare_kernel, dim3(kid_grid_for(b.n, 256, db->num_cu * 8)), dim3(256), 0, prep_stream, b, db->info.k,
-                       sc.desc, s->stats, sc.rare, ++s->batch_seq, nchunks ? sc.inval : nullptr);
+                       sc.desc, s->stats, sc.rare, ++s->batch_seq, nchunks ? sc.inval : nullptr, plan ? plan->cut : 0u);
     if (prep_stream != stream) {
         KID_HIP(hipEventRecord(sc.ev_prep, prep_stream));
         KID_HIP(hipStreamWaitEvent(stream, sc.ev_prep, 0));
@@ -790,6 +808,38 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
 #undef KID_LAUNCH_PK
 #undef KID_LAUNCH1
 #undef KID_LAUNCH
+    }
+    if (plan && !plan->recs.empty()) {
+        // the very long records: every k-mer looked up by a lane of its own, then one workgroup per record folds its hits
+        const uint64_t nrec = plan->recs.size();
+        if (nrec > s->long_recs_cap || plan->total_kmers > s->long_hits_cap || plan->n_tiles > s->long_tiles_cap) KID_HIP(hipDeviceSynchronize());
+        if (plan->n_tiles > s->long_tiles_cap) {
+            if (s->long_tiles) hipFree(s->long_tiles);
+            s->long_tiles = nullptr; s->long_tiles_cap = 0;
+            const uint64_t cap = plan->n_tiles + plan->n_tiles / 4 + 16;
+            KID_HIP(hipMalloc(&s->long_tiles, cap));
+            s->long_tiles_cap = cap;
+        }
+        if (nrec > s->long_recs_cap) {
+            if (s->long_recs) hipFree(s->long_recs);
+            s->long_recs = nullptr; s->long_recs_cap = 0;
+            KID_HIP(hipMalloc(&s->long_recs, nrec * sizeof(KidLongRec)));
+            s->long_recs_cap = nrec;
+        }
+        if (plan->total_kmers > s->long_hits_cap) {
+            if (s->long_hits) hipFree(s->long_hits);
+            s->long_hits = nullptr; s->long_hits_cap = 0;
+            const uint64_t cap = plan->total_kmers + plan->total_kmers / 4;
+            KID_HIP(hipMalloc(&s->long_hits, cap * 4));
+            s->long_hits_cap = cap;
+        }
+        KID_HIP(hipMemcpyAsync(s->long_recs, plan->recs.data(), nrec * sizeof(KidLongRec), hipMemcpyHostToDevice, stream));
+        KID_HIP(hipMemsetAsync(s->long_hits, 0, plan->total_kmers * 4, stream));
+        const uint64_t hgrid = plan->n_tiles < (uint64_t)db->num_cu * 8u ? plan->n_tiles : (uint64_t)db->num_cu * 8u;
+        hipLaunchKernelGGL(kid_long_hits_kernel, dim3((unsigned)hgrid), dim3(256), 0, stream, db->d, sc.codes, sc.inval, s->long_recs,
+                           (uint32_t)nrec, plan->n_tiles, s->long_hits, s->long_tiles, s->seen, s->stats);
+        hipLaunchKernelGGL(kid_long_fold_kernel, dim3((unsigned)nrec), dim3(256), 0, stream, db->d, s->long_recs, s->long_hits,
+                           s->long_tiles, s->gcount, b.out_final);
     }
     if (s->timing) {
         KID_HIP(hipEventRecord(ev1.e, stream));
@@ -927,6 +977,7 @@ static int kid_slot_acquire(kid_sample *s, uint64_t n_reads, uint64_t nbytes, bo
         KID_HIP(hipEventSynchronize(sl.ev_out));
         sl.busy = false;
     }
+    sl.plan = KidLongPlan();
     const uint64_t need = ((nbytes + 15) & ~15ull) + 32;
     if (need > sl.bases_cap) {
         if (sl.bases) KID_HIP(hipFree(sl.bases));
@@ -961,7 +1012,8 @@ static int kid_slot_submit(kid_sample *s, kid_sample::Slot &sl, const KidBatch &
     // classify kernels wait for them on the sample's stream
     KID_HIP(hipEventRecord(sl.ev_h2d, s->copy_stream));
     static const bool dbg_no_kernels = getenv("KID_DEBUG_NO_KERNELS") != nullptr; // timing experiments only
-    int rc = dbg_no_kernels ? KID_OK : kid_launch_classify(s, b, nbytes, s->stream, max_kmers, s->copy_stream);
+    int rc = dbg_no_kernels ? KID_OK : kid_launch_classify(s, b, nbytes, s->stream, max_kmers, s->copy_stream,
+                                                           sl.plan.recs.empty() ? nullptr : &sl.plan);
     if (rc != KID_OK) return rc;
     KID_HIP(hipEventRecord(sl.ev_done, s->stream));
     if (out_final_targ) {
@@ -985,17 +1037,35 @@ extern "C" int kid_classify_batch_async(kid_sample *s, const uint8_t *bases, con
     if (n_reads == 0) return KID_OK;
     if (!bases || !offsets) return kid_fail(KID_ERR_ARG, "null argument");
     if ((start == nullptr) != (stop == nullptr)) return kid_fail(KID_ERR_ARG, "start and stop must both be given or both be null");
-    int64_t max_kmers = 0;
+    // A record of more than `long_cut` k-mers is a long record (a FASTA contig, kmer_read_vf6.cpp:803-861): the classify
+    // kernels would give it to one wave.  If the batch holds few of them they go through the long-record kernels
+    // instead; if it holds many, the waves have enough of them to keep the chip busy as it is.
+    static const int64_t long_cut = getenv("KID_LONG_KMERS") ? atoll(getenv("KID_LONG_KMERS")) : 65536;
+    static const size_t long_max = 1024;
+    int64_t max_kmers = 0, max_short = 0;
+    std::vector<KidLongRec> longs;
     for (uint64_t r = 0; r < n_reads; r++) {
         if (offsets[r + 1] < offsets[r]) return kid_fail(KID_ERR_ARG, "offsets not monotone at read %llu", (unsigned long long)r);
         const uint64_t len = offsets[r + 1] - offsets[r];
         const int64_t span = start ? (int64_t)stop[r] - (int64_t)start[r] + 1 : (int64_t)len;
-        if (span - s->db->info.k + 1 > max_kmers) max_kmers = span - s->db->info.k + 1;
+        const int64_t nk = span - s->db->info.k + 1;
+        if (nk > max_kmers) max_kmers = nk;
         if (len > 0x7FFFFFFFull) return kid_fail(KID_ERR_ARG, "read %llu longer than 2^31-1", (unsigned long long)r);
         if (start && start[r] <= stop[r] && (start[r] < 0 || (uint64_t)stop[r] >= len))
             return kid_fail(KID_ERR_ARG, "read %llu: [start,stop] = [%d,%d] outside the read of length %llu (string::at would throw)",
                             (unsigned long long)r, start[r], stop[r], (unsigned long long)len);
+        if (long_cut > 0 && nk > long_cut) {
+            if (longs.size() <= long_max) {
+                KidLongRec lr;
+                lr.first_base = (offsets[r] - offsets[0]) + (uint64_t)(start ? start[r] : 0);
+                lr.hits_off = 0; lr.tile0 = 0;
+                lr.n_kmers = (uint32_t)nk;
+                lr.read = (uint32_t)r;
+                longs.push_back(lr);
+            }
+        } else if (nk > max_short) max_short = nk;
     }
+    const bool two_pass = !longs.empty() && longs.size() <= long_max && (int64_t)(uint32_t)long_cut == long_cut;
     int rc = kid_use_device(s->db->device);
     if (rc != KID_OK) return rc;
     const uint64_t base0 = offsets[0], nbytes = offsets[n_reads] - base0;
@@ -1004,6 +1074,18 @@ extern "C" int kid_classify_batch_async(kid_sample *s, const uint8_t *bases, con
     if (rc != KID_OK) return rc;
     kid_sample::Slot &sl = *slp;
     hipStream_t cs = s->copy_stream;
+    sl.plan = KidLongPlan();
+    if (two_pass) {
+        sl.plan.cut = (uint32_t)long_cut;
+        for (KidLongRec &lr : longs) {
+            lr.hits_off = sl.plan.total_kmers;
+            lr.tile0 = sl.plan.n_tiles;
+            sl.plan.total_kmers += lr.n_kmers;
+            sl.plan.n_tiles += ((uint64_t)lr.n_kmers + 255u) / 256u;
+        }
+        sl.plan.recs = std::move(longs);
+        max_kmers = max_short; // what the classify kernels get to see
+    }
     const uint64_t *off_src = offsets;
     if (base0 != 0) {
         sl.rel.resize(n_reads + 1);

@@ -306,7 +306,7 @@ __device__ __forceinline__ void kid_pack16(const uint4 v, const uint32_t u_is_t,
 // [start, stop] -> descriptor; the range checks the reference leaves to string::at() happen here
 // (runs after kid_pack_kernel: `inval` is the packed invalid-mask image of the batch)
 __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, unsigned long long *stats, KidRareArgs *rare, uint32_t seq,
-                                   const uint16_t *inval)
+                                   const uint16_t *inval, uint32_t long_cut)
 {
     // (descriptor / result pointers, the chunk counters and the device-clock stamps of the batch are set by
     //  kid_rebase_kernel in classify-stream order: this kernel may run while the batch before is being classified)
@@ -328,6 +328,9 @@ __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, u
         if (s0 > e0) nk = 0;
         d.first_base = off + (uint64_t)(s0 > 0 ? s0 : 0);
         d.n_kmers = (int32_t)(nk > 0x7FFFFFFF ? 0x7FFFFFFF : nk);
+        // a record the host hands to the long-record kernels (kid_long_hits_kernel / kid_long_fold_kernel): the classify
+        // kernels see a read without k-mers (counted under target 0 until the fold corrects that)
+        if (long_cut && nk > (int64_t)long_cut) d.n_kmers = 0;
         // pad bit 0: "some base of the read may reset a window" -- short reads are checked against the packed
         // mask (their 16-base chunks, a little more than the classified range), so that the classify kernel
         // need not fetch the mask of a clean read; longer reads are simply called dirty
@@ -1715,6 +1718,171 @@ __global__ void kid_build_firstwins_kernel(uint4 *table, uint32_t slot_mask, con
             }
         }
         if (copies > 1 && min_ord != (uint32_t)e + 1u) reinterpret_cast<uint32_t *>(table + my_idx)[1] = KID_TOMBSTONE_HI;
+    }
+}
+
+// ------------------------------------------------------------------ very long records (FASTA contigs classified whole)
+// A record is one left fold over its hits (newkmer_10nx.cpp:588-595; msca is not associative), which the classify
+// kernels run inside ONE wave: 9.7 ms per megabase when the batch holds few records.  When the host sees few long
+// records in a batch it hands them to two kernels instead:
+//   kid_long_hits_kernel   every k-mer of every long record is looked up by a lane of its own, all over the chip; a hit
+//                          leaves its target in hits[position] (and its bit in the seen-bitmap)
+//   kid_long_fold_kernel   one workgroup per record compacts the hits in position order and folds them, 64 at a time,
+//                          jumping from change to change of the running result like the resolver does
+// Plain code: this path runs a few hundred times per batch, not a hundred million times.
+struct KidLongRec {
+    uint64_t first_base; // absolute index of the record's first classified base in the batch text
+    uint64_t hits_off;   // where its hits start in the hits array
+    uint32_t n_kmers;
+    uint32_t read;       // its number in the batch
+    uint64_t tile0;      // number of 256-position tiles of the records before it
+};
+
+__device__ __forceinline__ uint32_t kid_codes_word(const uint32_t *codes, uint64_t w) { return codes[w]; }
+
+__global__ __launch_bounds__(256) void kid_long_hits_kernel(const KidDevDb db, const uint32_t *codes, const uint16_t *inval,
+                                                             const KidLongRec *recs, uint32_t n_recs, uint64_t n_tiles,
+                                                             uint32_t *hits, uint8_t *tile_any, uint32_t *seen,
+                                                             unsigned long long *stats)
+{
+    __shared__ uint32_t mm[256 + 32];
+    const int k = db.k;
+    const uint32_t win = (uint32_t)kid_min_window(k);
+    const int mlen = kid_min_mlen(k);
+    unsigned long long n_lookups = 0, n_cells = 0, n_hits = 0;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        // the record this tile belongs to (recs are few: binary search over tile0)
+        uint32_t lo = 0, hi = n_recs;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (recs[mid].tile0 <= tile) lo = mid; else hi = mid; }
+        const KidLongRec rc = recs[lo];
+        const uint32_t t0 = (uint32_t)(tile - rc.tile0) * 256u; // first k-mer of the tile within the record
+        const uint32_t j = threadIdx.x;
+        auto window = [&](uint64_t base) -> uint64_t { // 32 bases starting at `base`, first base in the top bits
+            const uint64_t w0 = base >> 4;
+            const uint32_t o2 = (uint32_t)(base & 15u) * 2u;
+            const uint64_t A = ((uint64_t)codes[w0] << 32) | codes[w0 + 1];
+            const uint64_t B = codes[w0 + 2];
+            return (A << o2) | ((B << o2) >> 32);
+        };
+        // hashed m-mers of positions t0 .. t0 + 255 + win - 1 (clamped to the last m-mer inside the record)
+        const uint64_t last_m = rc.first_base + (uint64_t)rc.n_kmers + (uint64_t)k - 1u - (uint64_t)mlen;
+        for (uint32_t q = j; q < 256u + win - 1u; q += 256u) {
+            uint64_t p = rc.first_base + t0 + q;
+            p = p < last_m ? p : last_m;
+            mm[q] = kid_mmer_hash((uint32_t)(window(p) >> (64 - 2 * mlen)), mlen);
+        }
+        __syncthreads();
+        const uint32_t i = t0 + j;
+        bool hit = false;
+        if (i < rc.n_kmers) {
+            const uint64_t p = rc.first_base + i;
+            // a window touching a base that is not ACGTacgt(Uu) holds no k-mer (newkmer_10nx.cpp:520-526,604)
+            const uint64_t c0 = p >> 4;
+            uint64_t im = (uint64_t)inval[c0] | ((uint64_t)inval[c0 + 1] << 16) | ((uint64_t)inval[c0 + 2] << 32);
+            im >>= (p & 15u);
+            if ((im & ((1ull << k) - 1ull)) == 0) {
+                const uint64_t keyF = window(p) >> (64 - 2 * k);
+                const uint64_t key = kid_canonical(keyF, k);
+                uint32_t slot = 0, nc = 0, tgt;
+                if (db.minloc) {
+                    uint32_t g = 0xFFFFFFFFu;
+                    for (uint32_t w = 0; w < win; w++) g = mm[j + w] < g ? mm[j + w] : g;
+                    tgt = kid_bucket_lookup(db, key, g, slot, nc);
+                } else {
+                    tgt = kid_dev_lookup(db, key, slot, nc);
+                }
+                n_lookups++;
+                n_cells += nc;
+                if (tgt > 0) {
+                    n_hits++;
+                    hit = true;
+                    hits[rc.hits_off + i] = tgt;
+                    if (tgt > 1) atomicOr(&seen[slot >> 5], 1u << (slot & 31u));
+                }
+            }
+        }
+        const int any = __syncthreads_or(hit ? 1 : 0); // (also: mm[] is free for the next tile)
+        if (threadIdx.x == 0) tile_any[tile] = any ? 1 : 0; // the fold skips tiles without hits unseen
+    }
+    // one set of atomics per workgroup (see kid_classify_kernel)
+    __shared__ unsigned long long tot[3];
+    if (threadIdx.x < 3) tot[threadIdx.x] = 0;
+    __syncthreads();
+    if (n_lookups) atomicAdd(&tot[0], n_lookups);
+    if (n_cells) atomicAdd(&tot[1], n_cells);
+    if (n_hits) atomicAdd(&tot[2], n_hits);
+    __syncthreads();
+    if (threadIdx.x < 3 && tot[threadIdx.x]) atomicAdd(&stats[1 + threadIdx.x], tot[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void kid_long_fold_kernel(const KidDevDb db, const KidLongRec *recs, const uint32_t *hits,
+                                                             const uint8_t *tile_any, unsigned long long *gcount,
+                                                             uint32_t *out_final)
+{
+    __shared__ uint32_t list[256];
+    __shared__ uint32_t wcount[4];
+    __shared__ uint8_t flags[256];
+    const KidLongRec rc = recs[blockIdx.x];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t uf = 0; // the running result (wave 0)
+    uint4 ufr = make_uint4(0, 0, 0, 0);
+    const uint32_t ntile = (rc.n_kmers + 255u) / 256u;
+    for (uint32_t tg = 0; tg < ntile; tg += 256u) { // 256 tiles = 65 536 positions at a time: most hold no hit at all
+      const uint32_t myt = tg + threadIdx.x;
+      const uint8_t fl = myt < ntile ? tile_any[rc.tile0 + myt] : (uint8_t)0;
+      flags[threadIdx.x] = fl;
+      if (!__syncthreads_or(fl)) continue;
+      for (uint32_t tt = 0; tt < 256u && tg + tt < ntile; tt++) {
+        if (!flags[tt]) continue; // (workgroup-uniform)
+        const uint32_t t0 = (tg + tt) * 256u;
+        {
+        const uint32_t i = t0 + threadIdx.x;
+        const uint32_t h = i < rc.n_kmers ? hits[rc.hits_off + i] : 0u;
+        const uint64_t bm = __ballot(h != 0);
+        if (lane == 0) wcount[wv] = (uint32_t)__popcll(bm);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t w = 0; w < 4; w++) { const uint32_t c = wcount[w]; if (w < wv) before += c; total += c; }
+        if (h != 0) list[before + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = h;
+        __syncthreads();
+        if (wv == 0) {
+            for (uint32_t c0 = 0; c0 < total; c0 += 64u) {
+                const uint32_t n = total - c0 < 64u ? total - c0 : 64u;
+                const uint32_t tgt = lane < n ? list[c0 + lane] : 0u;
+                uint4 row = make_uint4(0, 0, 0, 0);
+                if (db.rows && tgt) row = db.rows[tgt];
+                uint64_t rem = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
+                while (rem) { // every lane: the step its own hit would make from the current result; jump to the first change
+                    uint32_t rj = tgt;
+                    uint4 roj = row;
+                    if (uf != 0 && tgt != uf && tgt != 0) {
+                        if (db.rows) rj = kid_msca_rows(tgt, row, uf, ufr, roj);
+                        else rj = kid_msca_climb(db, tgt, uf);
+                    }
+                    const uint64_t ch = __ballot(rj != uf) & rem;
+                    if (!ch) break;
+                    const int jj = __builtin_ctzll(ch);
+                    uf = (uint32_t)__builtin_amdgcn_readlane((int)rj, jj);
+                    ufr.x = (uint32_t)__builtin_amdgcn_readlane((int)roj.x, jj);
+                    ufr.y = (uint32_t)__builtin_amdgcn_readlane((int)roj.y, jj);
+                    ufr.z = (uint32_t)__builtin_amdgcn_readlane((int)roj.z, jj);
+                    ufr.w = (uint32_t)__builtin_amdgcn_readlane((int)roj.w, jj);
+                    rem &= jj >= 63 ? 0ull : ~((2ull << jj) - 1ull);
+                }
+            }
+        }
+        __syncthreads();
+        }
+      }
+      __syncthreads(); // flags[] is rewritten by the next round
+    }
+    if (threadIdx.x == 0) {
+        // the classify kernels counted the record under target 0 (they saw it without k-mers)
+        if (uf != 0) {
+            atomicAdd(&gcount[uf], 1ull);
+            atomicAdd(&gcount[0], ~0ull); // - 1
+        }
+        if (out_final) out_final[rc.read] = uf;
     }
 }
 

@@ -593,6 +593,63 @@ def test_replicas_and_merged_end(seeded):
         r.close()
 
 
+def test_very_long_records_take_the_two_pass_path(seeded):
+    """FASTA contigs classified whole (kmer_read_vf6.cpp:803-861): records of more than 65536 k-mers in a host batch go
+    through kid_long_hits_kernel + kid_long_fold_kernel (every k-mer looked up by a lane of its own, one workgroup folds
+    a record's hits in position order) instead of being walked by one wave.  Same per-record results and counters as the
+    oracle's sequential fold: hits of several lineages in an order that matters, N and lower-case stretches, a start/stop
+    range, a record just above and one just below the threshold, short reads in between."""
+    parent, cum, keys, targets, odb, db = seeded
+    rng = np.random.default_rng(99)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+
+    def record(n_bases, every):
+        b = lut[rng.integers(0, 4, n_bases)].copy()
+        for p in range(500, n_bases - 40, every):   # DB k-mers of random targets, either strand: the fold order matters
+            v = int(keys[rng.integers(0, keys.size)])
+            if rng.random() < 0.5:
+                v = int(synth_revcomp(v))
+            b[p:p + 30] = np.frombuffer("".join("ACGT"[(v >> (2 * (29 - i))) & 3] for i in range(30)).encode(), np.uint8)
+        for p in rng.integers(0, n_bases - 50, 20):
+            b[p] = ord("N")
+        q = int(rng.integers(1000, n_bases - 2000))
+        b[q:q + 300] |= 0x20                         # a lower-case stretch
+        return b
+
+    def synth_revcomp(v):
+        r = 0
+        for i in range(30):
+            r = (r << 2) | (3 - ((v >> (2 * i)) & 3))
+        return r
+
+    recs = [record(200_000, 3000), synth.reads(cum, parent, 40, 150, K, r0=1), record(65536 + 29 + 1, 900),
+            record(65536 + 29, 900), record(300_000, 40), synth.reads(cum, parent, 25, 150, K, r0=77), record(90_000, 100_000)]
+    seqs = []
+    for r_ in recs:
+        if r_.size in (40 * 150, 25 * 150):
+            seqs += [r_[i * 150:(i + 1) * 150] for i in range(r_.size // 150)]
+        else:
+            seqs.append(r_)
+    bases = np.concatenate(seqs)
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    off[1:] = np.cumsum([x.size for x in seqs])
+    start = np.zeros(len(seqs), np.int32)
+    stop = np.array([x.size - 1 for x in seqs], np.int32)
+    start[0], stop[0] = 137, 199_000                 # a range inside the first long record
+    os_ = ob.OracleSample(odb)
+    exp = os_.classify(bases, off, start, stop)
+    eg, eu = os_.counts()
+    assert len(set(exp[[0, 41, 42, 43, len(seqs) - 1]].tolist())) > 1
+    s = db.sample()
+    got = s.classify(bases, off, start, stop)
+    assert np.array_equal(got, exp)
+    g, u = s.end()
+    assert np.array_equal(g, eg) and np.array_equal(u, eu)
+    st, est = s.stats(), os_.stats()
+    assert st["lookups"] == est["lookups"] and st["hits"] == est["hits"] and st["reads"] == len(seqs)
+    s.close()
+
+
 def test_async_host_batches_and_pinned_buffers(seeded):
     """kid_classify_batch_async / kid_classify_fixed_async / kid_classify_wait: more batches than staging slots in
     flight, ragged sizes, pinned (kid_host_alloc) and pageable buffers, waits out of order and twice, an empty batch;
