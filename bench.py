@@ -312,6 +312,9 @@ def main():
                                                                                  info.table_bytes / 2**30, build_s))
     nb = max(1, min(args.batches, args.steps + args.warmup))
     batches = [gen_reads(device, cum, parent, (rank * nb + b) * n_reads, n_reads) for b in range(nb)]
+    if os.environ.get("KID_BENCH_RANDOM_READS") == "1":  # development aid: reads without a single database k-mer (not the metric's workload)
+        lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=device)
+        batches = [lut[torch.randint(0, 4, (bt.numel(),), device=device)] for bt in batches]
     out_final = torch.empty(n_reads, dtype=torch.int32, device=device)
     sample = db.sample()
     # the batches are resident in HBM and final: the library may pack batch i + 1 while batch i is being classified
@@ -404,10 +407,12 @@ def main():
 
     extra = {}
     if args.gather and rank == 0:
-        for inflight in (1, 4):
-            ms, loads = db.gather_ceiling(n_loads=1 << 29, inflight=inflight, iters=3)
-            extra["gather16B_%d_inflight_GBps" % inflight] = round(loads * 16 / (ms / 1e3) / 1e9, 1)
-            extra["gather16B_%d_inflight_Gloads_per_s" % inflight] = round(loads / (ms / 1e3) / 1e9, 2)
+        # what the memory system gives a kernel that does nothing but ask for random 128-byte lines of THIS table with
+        # the classify kernel's load (one 16-byte header per lane, runs of 8 lanes on a line / 64 lines per load)
+        for name, code in (("runs_of_8", 108), ("64_per_load", 101)):
+            ms, lines = db.gather_ceiling(n_loads=1 << 29, inflight=code, iters=3)
+            extra["random_lines_%s_Glines_per_s" % name] = round(lines / (ms / 1e3) / 1e9, 2)
+            extra["random_lines_%s_GBps_of_128B" % name] = round(lines * 128 / (ms / 1e3) / 1e9, 1)
 
     host_leg = e2e_leg = None
     if rank == 0 and world == 1 and args.config == "1m":

@@ -220,10 +220,15 @@ int kid_synth_reads_device(uint64_t db_seed, uint64_t read_seed, int k, const ui
                            const int32_t *parent_host, int32_t ntar, uint64_t r0, uint64_t n_reads,
                            uint32_t read_len, void *d_bases, int device);
 
-/* random 16-byte gather micro-benchmark over the DB's own table: the measured
- * ceiling the lookup kernel is priced against.  n_loads random cells are read,
- * `inflight` (1,2,4,8) independent loads per lane; *ms_out = milliseconds per
- * launch, *loads_out = loads one launch issued.                                   */
+/* random gather micro-benchmark over the DB's own table: the measured ceiling the
+ * lookup kernel is priced against.  inflight = 101 / 108: random 128-byte LINES,
+ * one 16-byte load per lane as the classify kernel issues it (64 distinct lines per
+ * load / runs of 8 lanes on a line), four loads in flight per lane; *loads_out = the
+ * distinct line requests of one launch.  inflight = 1,2,4,8: n_loads random cells,
+ * that many independent loads per lane, of which the compiler keeps two 4-byte
+ * loads per cell (the round-1 probe: twice the load instructions per line, it tops
+ * out at 39 G cells/s where the line probe reaches 49 G lines/s).
+ * *ms_out = milliseconds per launch.                                               */
 int kid_bench_gather(kid_db *db, uint64_t n_loads, int inflight, int iters, float *ms_out, uint64_t *loads_out);
 
 /* device memory helpers so that a host language without a HIP binding can stage buffers */

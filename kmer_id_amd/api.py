@@ -127,7 +127,9 @@ class KmerDB:
         return start, stop, keep
 
     def gather_ceiling(self, n_loads=1 << 28, inflight=4, iters=3):
-        """Random 16-byte gather rate over this DB's table: (ms per launch, loads per launch)."""
+        """Random gather rate over this DB's table: (ms per launch, loads per launch).  inflight 101 / 108: random
+        128-byte lines asked for the way the classify kernel asks (64 per load / runs of 8 lanes), 4 loads in flight;
+        1, 2, 4, 8: the round-1 cell probe (see include/kmer_id_amd.h)."""
         ms = C.c_float(0)
         loads = C.c_uint64(0)
         check(self._lib.kid_bench_gather(self._h, n_loads, inflight, iters, C.byref(ms), C.byref(loads)))

@@ -1495,8 +1495,12 @@ extern "C" int kid_bench_gather(kid_db *db, uint64_t n_loads, int inflight, int 
     if (rc != KID_OK) return rc;
     const int block = 256, grid = db->num_cu * 8;
     const uint64_t lanes = (uint64_t)block * grid;
-    if (inflight != 1 && inflight != 2 && inflight != 4 && inflight != 8) return kid_fail(KID_ERR_ARG, "inflight must be 1,2,4 or 8");
-    uint64_t rounds = n_loads / (lanes * (uint64_t)inflight);
+    // inflight = 101 / 108: random LINES, runs of 1 / 8 lanes on a line, 4 loads in flight (kid_gather_lines_kernel);
+    // *loads_out is then the number of distinct line requests
+    const bool by_line = inflight == 101 || inflight == 108 || inflight == 111 || inflight == 121 || inflight == 131; // (1x1: development variants, see the kernel)
+    if (!by_line && inflight != 1 && inflight != 2 && inflight != 4 && inflight != 8) return kid_fail(KID_ERR_ARG, "inflight must be 1,2,4 or 8 (or 101, 108: by line)");
+    if (by_line && db->d.slot_mask < 7u) return kid_fail(KID_ERR_ARG, "table too small");
+    uint64_t rounds = n_loads / (lanes * (uint64_t)(by_line ? 4 : inflight));
     if (rounds < 1) rounds = 1;
     KidDevBuf sinkb;
     KID_HIP(sinkb.alloc(16));
@@ -1506,7 +1510,13 @@ extern "C" int kid_bench_gather(kid_db *db, uint64_t n_loads, int inflight, int 
     KID_HIP(ev1.create());
     const hipEvent_t e0 = ev0.e, e1 = ev1.e;
     auto launch = [&]() {
+        const uint32_t line_mask = db->d.slot_mask >> 3;
         switch (inflight) {
+        case 101: hipLaunchKernelGGL((kid_gather_lines_kernel<1>), dim3(grid), dim3(block), 0, 0, db->table, line_mask, rounds, sink); break;
+        case 111: hipLaunchKernelGGL((kid_gather_lines_kernel<1, 1>), dim3(grid), dim3(block), 0, 0, db->table, line_mask, rounds, sink); break;
+        case 121: hipLaunchKernelGGL((kid_gather_lines_kernel<1, 2>), dim3(grid), dim3(block), 0, 0, db->table, line_mask, rounds, sink); break;
+        case 131: hipLaunchKernelGGL((kid_gather_lines_kernel<1, 3>), dim3(grid), dim3(block), 0, 0, db->table, line_mask, rounds, sink); break;
+        case 108: hipLaunchKernelGGL((kid_gather_lines_kernel<8>), dim3(grid), dim3(block), 0, 0, db->table, line_mask, rounds, sink); break;
         case 1: hipLaunchKernelGGL((kid_gather_kernel<1>), dim3(grid), dim3(block), 0, 0, db->table, db->d.slot_mask, rounds, sink); break;
         case 2: hipLaunchKernelGGL((kid_gather_kernel<2>), dim3(grid), dim3(block), 0, 0, db->table, db->d.slot_mask, rounds, sink); break;
         case 4: hipLaunchKernelGGL((kid_gather_kernel<4>), dim3(grid), dim3(block), 0, 0, db->table, db->d.slot_mask, rounds, sink); break;
@@ -1522,7 +1532,7 @@ extern "C" int kid_bench_gather(kid_db *db, uint64_t n_loads, int inflight, int 
     float ms = 0;
     KID_HIP(hipEventElapsedTime(&ms, e0, e1));
     *ms_out = ms / (float)iters;
-    *loads_out = rounds * lanes * (uint64_t)inflight; // loads actually issued per launch
+    *loads_out = by_line ? rounds * (lanes / (inflight == 108 ? 8 : 1)) * 4 : rounds * lanes * (uint64_t)inflight; // loads (lines) actually asked for per launch
     return KID_OK;
 }
 

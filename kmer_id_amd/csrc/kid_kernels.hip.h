@@ -26,6 +26,17 @@
 #define KID_CQ_CAP 192   // a read appends at most 128 entries to fewer than KID_CQ_FLUSH queued ones
 #define KID_CQ_FLUSH 64
 #define KID_PAIR_LDS_WORDS (4 + 3 * KID_CQ_CAP + KID_CQ_CAP / 4 + 64 + 128) // ... + the batch read numbers of 128 result slots
+#ifndef KID_WORDS_MASKED
+#define KID_WORDS_MASKED 1 // pair kernels: the packed words of a read are requested by the lanes that hold words of it only
+#endif
+#ifndef KID_ROW_WORDS
+#define KID_ROW_WORDS 0 // pair kernel, 1: packed words by DPP row broadcasts instead of ds_bpermute (needs KID_WORDS_MASKED).
+                        // Bit-exact and 16 LDS instructions per pair fewer, but not faster (profiles/r02/ab_row_words.txt): kept as a switch
+#endif
+#ifndef KID_SKEW
+#define KID_SKEW 0 // pair loop, 1: the second read's header test is taken in the next trip (see the loop); 0: straight order.
+                   // Bit-exact, no faster (profiles/r02/ab_skew.txt: the loop is not bound by the wait for those headers)
+#endif
 #ifndef KID_DYNAMIC
 // 1: the waves of the pair kernel draw their reads in small blocks from counters instead of owning a fixed share.
 // Measured (profiles/r02/dynamic_blocks.txt): the SIMDs serve their oldest waves first, so with fixed shares the waves of
@@ -33,6 +44,14 @@
 // not shorten the launch: the starved (young) waves hold their last blocks for hundreds of microseconds, and every
 // block switch costs a drain.  Off by default; the code stays for the next attempt.
 #define KID_DYNAMIC 0
+#endif
+#ifndef KID_EARLY_CAND
+// 1: a lookup whose header shows a fingerprint match fetches its candidate cell on the spot -- the cell sits in the
+// 128-byte line the header has just brought in -- and the queue carries {target, entry ordinal} of verified hits; the
+// resolver then needs neither the header nor the cell again (by then the line is long gone from every cache: one HBM
+// line and two dependent round trips per hit saved).  Lookups that cannot be settled by their first candidate (a
+// fingerprint false positive, a full line) are queued the old way.
+#define KID_EARLY_CAND 1
 #endif
 #define KID_DYN_SHARDS 16u // counters the chunks are drawn from (one word takes ~90 fetches per microsecond)
 #ifndef KID_DYN_CHUNK
@@ -52,6 +71,11 @@
 #endif
 #ifndef KID_CLASSIFY_OCC
 #define KID_CLASSIFY_OCC 8 // waves per SIMD the register allocator must leave room for
+#endif
+#ifdef KID_CLASSIFY_VGPR // experiment: a VGPR cap of its own (with KID_CLASSIFY_OCC = 7: 96 SGPRs, but still 64 VGPRs)
+#define KID_CLASSIFY_ATTR __attribute__((amdgpu_num_vgpr(KID_CLASSIFY_VGPR)))
+#else
+#define KID_CLASSIFY_ATTR
 #endif
 
 typedef uint32_t kid_u4 __attribute__((ext_vector_type(4)));
@@ -165,6 +189,9 @@ __device__ __forceinline__ uint32_t kid_hdr_cand(const uint4 &h, uint32_t fp)
 __device__ __forceinline__ bool kid_hdr_any(const uint4 &h, uint32_t fp)
 {
     const uint16_t f = (uint16_t)fp;
+#ifdef KID_ABLATE_HDR1 // timing experiment only (misses six of seven entries): is the loop sensitive to its VALU instruction count?
+    return (uint16_t)h.x == f;
+#endif
     return ((uint16_t)h.x == f) | ((uint16_t)(h.x >> 16) == f) | ((uint16_t)h.y == f) | ((uint16_t)(h.y >> 16) == f) |
            ((uint16_t)h.z == f) | ((uint16_t)(h.z >> 16) == f) | ((uint16_t)h.w == f);
 }
@@ -219,23 +246,86 @@ __device__ __forceinline__ uint32_t kid_dev_lookup(const KidDevDb &db, uint64_t 
 // ------------------------------------------------------------------ sliding-window minimum over a wavefront
 // 16-lane DPP rows double as the blocks of the van Herk / Gil-Werman scheme: with P = prefix
 // minimum and S = suffix minimum inside each row, min(a[p..p+15]) = min(S[p], P[p+15]).
+#ifndef KID_DPP_ASM
+#define KID_DPP_ASM 0 // 1: the scans as hand-written v_min_u32_dpp sequences (hipcc left the last step of a scan as mov + mov_dpp + min)
+#endif
+// (a lane whose DPP source lies outside its row is disabled for that instruction: it keeps its own value.  A VGPR written
+//  by a VALU instruction may be read through DPP two wait states later: s_nop 1 between dependent steps of ONE scan;
+//  kid_row_scans interleaves four scans instead)
 __device__ __forceinline__ uint32_t kid_row_prefix_min(uint32_t x)
 {
+#if KID_DPP_ASM
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(x));
+    return x;
+#else
     uint32_t t;
     t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x111, 0xF, 0xF, false); x = x < t ? x : t; // row_shr:1
     t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x112, 0xF, 0xF, false); x = x < t ? x : t;
     t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x114, 0xF, 0xF, false); x = x < t ? x : t;
     t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x118, 0xF, 0xF, false); x = x < t ? x : t;
     return x;
+#endif
 }
 __device__ __forceinline__ uint32_t kid_row_suffix_min(uint32_t x)
 {
+#if KID_DPP_ASM
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(x));
+    return x;
+#else
     uint32_t t;
     t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x101, 0xF, 0xF, false); x = x < t ? x : t; // row_shl:1
     t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x102, 0xF, 0xF, false); x = x < t ? x : t;
     t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x104, 0xF, 0xF, false); x = x < t ? x : t;
     t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x108, 0xF, 0xF, false); x = x < t ? x : t;
     return x;
+#endif
+}
+// prefix and suffix minima of two tiles at once: p0 = s0 = hashes of the first tile, p1 = s1 = those of the second
+__device__ __forceinline__ void kid_row_scans(uint32_t &p0, uint32_t &s0, uint32_t &p1, uint32_t &s1)
+{
+#if KID_DPP_ASM
+#define KID_SCAN4(n)                                                                                                    \
+    "v_min_u32_dpp %0, %0, %0 row_shr:" #n " row_mask:0xf bank_mask:0xf\n\t"                                            \
+    "v_min_u32_dpp %1, %1, %1 row_shl:" #n " row_mask:0xf bank_mask:0xf\n\t"                                            \
+    "v_min_u32_dpp %2, %2, %2 row_shr:" #n " row_mask:0xf bank_mask:0xf\n\t"                                            \
+    "v_min_u32_dpp %3, %3, %3 row_shl:" #n " row_mask:0xf bank_mask:0xf\n\t"
+    asm("s_nop 1\n\t" KID_SCAN4(1) KID_SCAN4(2) KID_SCAN4(4) KID_SCAN4(8) "s_nop 1" : "+v"(p0), "+v"(s0), "+v"(p1), "+v"(s1));
+#undef KID_SCAN4
+#else
+    p0 = kid_row_prefix_min(p0); s0 = kid_row_suffix_min(s0);
+    p1 = kid_row_prefix_min(p1); s1 = kid_row_suffix_min(s1);
+#endif
+}
+
+// ------------------------------------------------------------------ packed words of a read without the LDS crossbar
+// Pair kernel: lane 16 r + j of `w` holds packed word r + j of a read (see issue_words).  The 64 windows of tile K0/4
+// start at base sh + 16 K0 + lane: the lanes of row r want the words K0 + r + {0, 1, 2} of the read, or one further
+// (`hi`: the lane's window begins in the second word of its row) -- four row broadcasts (DPP row_newbcast: a VALU move)
+// and three selects, where ds_bpermute took three trips through the LDS crossbar per tile.  Those were what bounded the
+// loop: 16 of them per pair cost 0.21 of 0.87 ms (profiles/r02/ab_nobperm.txt).
+template <int N>
+__device__ __forceinline__ uint32_t kid_row_bcast(uint32_t w)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x150 + N, 0xF, 0xF, false); // row_newbcast:N
+}
+template <int K0>
+__device__ __forceinline__ void kid_row_words(uint32_t w, bool hi, uint64_t &A, uint64_t &B)
+{
+    const uint32_t r0 = kid_row_bcast<K0>(w), r1 = kid_row_bcast<K0 + 1>(w), r2 = kid_row_bcast<K0 + 2>(w), r3 = kid_row_bcast<K0 + 3>(w);
+    A = ((uint64_t)(hi ? r1 : r0) << 32) | (hi ? r2 : r1);
+    B = hi ? r3 : r2;
+}
+template <int K0>
+__device__ __forceinline__ uint64_t kid_row_words2(uint32_t w, bool hi) // two words: enough for an m-mer
+{
+    const uint32_t r0 = kid_row_bcast<K0>(w), r1 = kid_row_bcast<K0 + 1>(w), r2 = kid_row_bcast<K0 + 2>(w);
+    return ((uint64_t)(hi ? r1 : r0) << 32) | (hi ? r2 : r1);
 }
 
 // ------------------------------------------------------------------ taxonomy
@@ -422,7 +512,7 @@ struct KidGroup {      // a group of U*64 windows between its two halves
 // batch is for when it knows the longest read, else all three: the others return at once.  Separate
 // kernels, because each loop wants all 64 vector registers of an 8-waves-per-SIMD kernel for itself.
 template <int U, bool ROWS, bool HIST, bool MINLOC, int KFIX, int PAIRK>
-__global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(const KidDevDb db, const KidPacked b, const KidSampleDev s,
+__global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_classify_kernel(const KidDevDb db, const KidPacked b, const KidSampleDev s,
                                                             const uint32_t hist_words,
                                                             const KidReadDesc *__restrict__ const descs,
                                                             const KidRareArgs *__restrict__ const rare)
@@ -533,6 +623,9 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         // instead of write + barrier + read.  Needs the whole read inside 64 words, which a group is.
         const bool direct = (W == nullptr);
         auto word = [&](const uint32_t idx) -> uint32_t {
+#ifdef KID_ABLATE_BPERM // timing experiment only (wrong k-mers): how much of the front half is the LDS crossbar?
+            if (direct) return (wcodes ^ idx) * 0x9E3779B1u;
+#endif
             return direct ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)wcodes) : W[idx];
         };
         auto mask32 = [&](const uint32_t idx) -> uint32_t { // invalid-mask bits of bases 32 idx .. 32 idx + 31
@@ -541,7 +634,19 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx << 3) + 4u), (int)winv);
             return (lo & 0xFFFFu) | (hi << 16);
         };
+        // pair kernel: the words come row-wise (kid_row_words); the windows of lanes past the read's end then hold the bases
+        // that follow it in the packed image -- no k-mer of the read looks at their m-mers
+        const bool rowmode = direct && PAIRK == 1 && KID_ROW_WORDS;
+        const bool hiw = (lane & 15u) + sh >= 16u;
         uint32_t P[U + 1], S[U]; // minloc: row prefix / suffix minima of the hashed m-mers
+#ifdef KID_ABLATE_EXTRA_VALU // timing experiment only: how sensitive is the loop to its VALU instruction count?
+        {
+            uint32_t dummy = lane;
+#pragma unroll
+            for (int e = 0; e < KID_ABLATE_EXTRA_VALU; e++) asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(dummy));
+            asm volatile("" : : "v"(dummy));
+        }
+#endif
         const uint32_t pmax = sh + nb - (uint32_t)mlen; // last m-mer start inside the segment
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -550,10 +655,16 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             // lanes past the last k-mer still hash their m-mer (the windows of earlier lanes reach
             // 14 positions ahead), clamped to the last one that lies inside the segment
             uint32_t p = sh + i;
-            p = MINLOC ? (p < pmax ? p : pmax) : sh + (i < segk ? i : 0u);
+            if (!rowmode) p = MINLOC ? (p < pmax ? p : pmax) : sh + (i < segk ? i : 0u);
             const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
-            const uint64_t A = ((uint64_t)word(w0) << 32) | word(w0 + 1);
-            const uint64_t B = word(w0 + 2);
+            uint64_t A, B;
+            if (rowmode) {
+                if (u == 0) kid_row_words<0>(wcodes, hiw, A, B);
+                else kid_row_words<4>(wcodes, hiw, A, B);
+            } else {
+                A = ((uint64_t)word(w0) << 32) | word(w0 + 1);
+                B = word(w0 + 2);
+            }
             const uint64_t x = (A << o2) | ((B << o2) >> 32);
             const uint64_t keyF = x >> (64 - 2 * k);
             // one reversal of the 32-base window serves both reverse complements: base j of the window
@@ -572,8 +683,15 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             g.act[u] = valid;
             if (MINLOC && !KID_ABLATE_NOMIN) {
                 const uint32_t h = kid_mmer_hash2((uint32_t)(x >> (64 - 2 * mlen)), (uint32_t)nrv & (0xFFFFFFFFu >> (32 - 2 * mlen)));
-                P[u] = kid_row_prefix_min(h);
-                S[u] = kid_row_suffix_min(h);
+                P[u] = h;
+                S[u] = h;
+            }
+        }
+        if (MINLOC && !KID_ABLATE_NOMIN) {
+            if constexpr (U == 2) kid_row_scans(P[0], S[0], P[1], S[1]);
+            else {
+#pragma unroll
+                for (int u = 0; u < U; u++) { P[u] = kid_row_prefix_min(P[u]); S[u] = kid_row_suffix_min(S[u]); }
             }
         }
 #if defined(KID_ABLATE) && KID_ABLATE >= 2
@@ -587,11 +705,15 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             // the win-1 m-mers behind the last k-mer of the group -- if any window of the group reaches that
             // far (wave-uniform: a 100-bp read ends inside the group, m-mers and all)
             P[U] = 0xFFFFFFFFu;
+#ifdef KID_ABLATE_NOTAIL // timing experiment only (wrong minimizers for the last windows of a read)
+            if (false) {
+#else
             if (segk + win - 1u > t0 + (uint32_t)U * 64u) {
+#endif
                 uint32_t p = sh + t0 + (uint32_t)U * 64u + lane;
-                p = p < pmax ? p : pmax;
+                if (!rowmode) p = p < pmax ? p : pmax;
                 const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
-                const uint64_t A = ((uint64_t)word(w0) << 32) | word(w0 + 1);
+                const uint64_t A = rowmode ? kid_row_words2<4 * U>(wcodes, hiw) : ((uint64_t)word(w0) << 32) | word(w0 + 1);
                 P[U] = kid_row_prefix_min(kid_mmer_hash((uint32_t)((A << o2) >> (64 - 2 * mlen)), mlen));
             }
             // ... and their minimum over every window a[p..p+win-1].  With q = p mod 16: the window
@@ -841,12 +963,15 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             const bool valid = lane < n;
             uint32_t klo = 0, khi = 0, ln = 0, tag = 0;
             if (valid) { klo = CQ_klo[base + lane]; khi = CQ_khi[base + lane]; ln = CQ_lw[base + lane]; tag = CQ_tag[base + lane]; }
+            const bool verified = KID_EARLY_CAND && (tag & 0x80u) != 0; // {target, entry ordinal} fetched when the header came in
+            tag &= 63u;
             // the header once more (the queue keeps only the line: working out the candidates at
             // queueing time would cost the hot loop ~45 instructions per read with a match)
             uint32_t tgt = 0, slot = 0, mu = 0;
             const uint32_t fp = kid_key_fp(((uint64_t)khi << 32) | klo);
             bool fu = false;
-            if (valid) {
+            if (verified) { tgt = klo; slot = khi; }
+            if (valid && !verified) {
                 const uint4 h = kid_load_cell(db.table, ln * KID_LINE_CELLS);
                 mu = kid_hdr_cand(h, fp);
                 fu = kid_hdr_continues(h.w, fp);
@@ -861,7 +986,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                 const uint4 c = kid_load_cell(db.table, idx);
                 if (c.z != 0 && c.x == klo && c.y == khi) { tgt = c.z; slot = c.w - 1u; }
             }
-            bool go = valid && tgt == 0 && (mu != 0 || fu);
+            bool go = valid && !verified && tgt == 0 && (mu != 0 || fu);
             while (go) { // a second candidate (1e-4 of the lookups) or a chained line (1e-5)
                 if (mu) {
                     const uint32_t j = kid_cand_entry((uint32_t)__builtin_ctz(mu));
@@ -1013,12 +1138,23 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         for (int u = 0; u < U; u++) {
             const uint64_t qm = __ballot(mm[u]);
             if (qm == 0) continue;
+            const uint32_t cm = (KID_EARLY_CAND && mm[u]) ? kid_hdr_cand(g.hd[u], fp[u]) : 0u;
+            if (KID_EARLY_CAND) { // (cells read: one add for the wave)
+                const uint64_t cmb = __ballot(cm != 0);
+                if (cmb && lane == 0) atomicAdd(&WC[3], (uint32_t)__popcll(cmb));
+            }
             if (mm[u]) {
                 const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
-                CQ_klo[pos] = (uint32_t)g.key[u];
-                CQ_khi[pos] = (uint32_t)(g.key[u] >> 32);
+                uint32_t w0 = (uint32_t)g.key[u], w1 = (uint32_t)(g.key[u] >> 32), tagv = i & 63u;
+                if (cm) { // the first candidate, while its line is in the cache
+                    const uint32_t idx = g.hlo[u] * KID_LINE_CELLS + 1u + kid_cand_entry((uint32_t)__builtin_ctz(cm));
+                    const uint4 c = kid_load_cell(db.table, idx);
+                    if (c.z != 0 && c.x == w0 && c.y == w1) { w0 = c.z; w1 = c.w - 1u; tagv |= 0x80u; } // verified: {target, ordinal}
+                }
+                CQ_klo[pos] = w0;
+                CQ_khi[pos] = w1;
                 CQ_lw[pos] = g.hlo[u];
-                CQ_tag[pos] = (uint8_t)(i & 63u);
+                CQ_tag[pos] = (uint8_t)tagv;
             }
             qn += (uint32_t)__popcll(qm);
         }
@@ -1156,6 +1292,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
     if constexpr (PAIRK != 0) {
         const uint32_t cnt = gw < b.n ? (uint32_t)((b.n - gw + nw - 1) / nw) : 0u; // reads of this wave: gw + i nw
         const uint32_t lane4 = lane * 4u;
+        const uint32_t lane4row = ((lane >> 4) + (lane & 15u)) * 4u; // byte offset of the word a lane holds when words come row-wise
         // descriptors, 64 at a time: lane l holds the one of read number blk + l of this wave -- the low word
         // of first_base, and its high word (< 2^16: a batch is smaller than 2^48 bytes) with n_kmers (<= 128
         // in this kernel) above it
@@ -1185,8 +1322,25 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
             const uint32_t *const pc = b.codes + w0;
             const uint16_t *const pi = (hn >> 31) ? b.inval + w0 : b.inval; // clean read: any cached line will do, the mask is not looked at
 #endif
+#if KID_WORDS_MASKED
+            // A read of the pair kernel (<= 128 k-mers, k <= 32, behind a shift of <= 15 bases) lies in its first 12 packed
+            // words, one of the duo kernel (<= 256 k-mers) in its first 20: only those lanes ask -- one or two 64-byte
+            // segments per request instead of four and two.  The other lanes keep their zeros.  (The mask is applied
+            // inside the statement: the compiler must not see a load in a branch of its own.)
+            const uint64_t word_lanes = PAIRK == 1 ? 0xFFFull : 0xFFFFFull;
+            uint64_t save;
+            if (PAIRK == 1 && KID_ROW_WORDS) {
+                // row-wise: lane 16 r + j asks for word r + j (j <= 10: tile 1 of row 3 reaches word 10, the m-mers behind
+                // the last tile words 8..10 of row 0); the masks keep the lane = word order (only unclean reads look at them)
+                asm volatile("s_mov_b64 %2, exec\n\ts_mov_b64 exec, %5\n\tglobal_load_dword %0, %3, %4\n\ts_mov_b64 exec, %8\n\tglobal_load_ushort %1, %6, %7\n\ts_mov_b64 exec, %2"
+                             : "+v"(c), "+v"(iv), "=&s"(save) : "v"(lane4row), "s"(pc), "s"(0x07FF07FF07FF07FFull), "v"(lane4 >> 1), "s"(pi), "s"(word_lanes) : "memory");
+            } else
+            asm volatile("s_mov_b64 %2, exec\n\ts_mov_b64 exec, %5\n\tglobal_load_dword %0, %3, %4\n\tglobal_load_ushort %1, %6, %7\n\ts_mov_b64 exec, %2"
+                         : "+v"(c), "+v"(iv), "=&s"(save) : "v"(lane4), "s"(pc), "s"(word_lanes), "v"(lane4 >> 1), "s"(pi) : "memory");
+#else
             asm volatile("global_load_dword %0, %1, %2" : "=v"(c) : "v"(lane4), "s"(pc) : "memory");
             asm volatile("global_load_ushort %0, %1, %2" : "=v"(iv) : "v"(lane4 >> 1), "s"(pi) : "memory");
+#endif
         };
         auto issue_header = [&](const KidGroup<U> &g, const int u) -> kid_u4 {
             const uint4 *const p = db.table + (g.act[u] ? g.hlo[u] * KID_LINE_CELLS : 0u);
@@ -1198,7 +1352,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
 #endif
             return v;
         };
-        uint32_t cA, iA, cB, iB;
+        uint32_t cA = 0, iA = 0, cB = 0, iB = 0;
         if constexpr (PAIRK == 2) {
             load_block();
             issue_words(0u, cA, iA);
@@ -1339,6 +1493,88 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
 #endif
         switch_block();
         bool more = blen != 0;
+#if KID_SKEW
+        // Skewed schedule.  The header test of a pair's second read (B) waits for the NEXT trip, between the front halves of
+        // the next pair: front A, [test of the previous B], front B, test A.  In the straight order (front A, front B,
+        // test A, test B) the headers of B were asked for one short test before they were needed, and every trip of every
+        // wave sat out most of a round trip to HBM there; now both header requests of a trip are half a trip old when
+        // their wait comes.  Register pressure is that of the straight order's front B (one read's keys, fingerprints and
+        // headers live during the other read's front half).  Queue entries stay in read order: A_i, B_i, A_i+1.
+        KidGroup<U> gB;
+        gB.act[0] = false; gB.act[1] = false; gB.hlo[0] = 0; gB.hlo[1] = 0; gB.fpp = 0; gB.key[0] = 0; gB.key[1] = 0;
+        gB.hd[0] = make_uint4(0, 0, 0, 0); gB.hd[1] = make_uint4(0, 0, 0, 0);
+        kid_u4 hB0 = {0, 0, 0, 0}, hB1 = {0, 0, 0, 0};
+        bool pendB = false; // the previous pair's B is a real read whose headers have not been looked at
+        if (more) {
+            // two stand-ins for "the headers of the previous B" (cell 0, nobody looks at them): the explicit counts of
+            // the first trip are then those of every trip
+            issue_words(0u, cA, iA);
+            hB0 = issue_header(gB, 0); hB1 = issue_header(gB, 1);
+            issue_words(1u, cB, iB);
+        }
+        auto test_B = [&](const uint32_t iB_) {
+            gB.hd[0] = make_uint4(hB0.x, hB0.y, hB0.z, hB0.w);
+            gB.hd[1] = make_uint4(hB1.x, hB1.y, hB1.z, hB1.w);
+            if (!back_deferred(gB, iB_)) commit_zero(iB_);
+            else if (qn >= KID_CQ_FLUSH) resolve_all(iB_, 0xFFFFFFFFu);
+        };
+        while (more) {
+            const uint32_t i = seq;
+            const uint32_t ia = i - blk;
+            const uint32_t hnA = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)ia), hnB = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)(ia + 1u));
+            const uint32_t nkA = (hnA >> 16) & 0x7FFFu, nkB = (hnB >> 16) & 0x7FFFu;
+            const uint32_t shA = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)ia) & 15u;
+            const uint32_t shB = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)(ia + 1u)) & 15u;
+            const bool realB = ia + 1u < blen; // (a block with an odd number of reads -- the last of a pool: B is a phantom of zero k-mers)
+            KidGroup<U> gA;
+            uint32_t badA = 0, badB = 0;
+            // the block's last pair: the next block's descriptors (this pair's are in scalars by now)
+            if (ia + 2u >= blen) {
+                blk = i + 2u;
+                switch_block(); // (no block: all-zero descriptors, the word requests below fetch what nobody needs)
+                more = blen != 0;
+            }
+
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(cA), "+v"(iA) : : "memory"); // behind: the headers of the previous B, the words of B
+            const bool clA = !(hnA >> 31) || (__ballot(iA != 0) == 0); // no base of the read resets a window
+            group_front(nullptr, shA, nkA + (uint32_t)k - 1, nkA, 0u, clA, gA, badA, false, cA, iA);
+            kid_u4 hA0 = issue_header(gA, 0), hA1 = issue_header(gA, 1);
+            issue_words(i + 2u - blk, cA, iA); // the packed words of the next pair, a whole trip ahead (they come from HBM)
+            n_lookups += nkA - badA;
+
+            asm volatile("s_waitcnt vmcnt(6)" : "+v"(hB0), "+v"(hB1) : : "memory"); // behind: the words of B, headers and next words of A
+            if (pendB) test_B(i - 1u);
+            if ((i & 63u) == 0u && i != 0u) { // tags and result slots are wave-local read numbers mod 64
+                if (qn) resolve_all(i - 1u, 0xFFFFFFFFu);
+                flush_results(i - 64u, 64u);
+            }
+
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(cB), "+v"(iB) : : "memory"); // behind: headers and next words of A
+            const bool clB = !(hnB >> 31) || (__ballot(iB != 0) == 0);
+            group_front(nullptr, shB, nkB + (uint32_t)k - 1, nkB, 0u, clB, gB, badB, false, cB, iB);
+            hB0 = issue_header(gB, 0); hB1 = issue_header(gB, 1);
+            issue_words(i + 3u - blk, cB, iB);
+            pendB = realB;
+            nreal += realB ? 2u : 1u;
+            if (realB) n_lookups += nkB - badB;
+
+            asm volatile("s_waitcnt vmcnt(6)" : "+v"(hA0), "+v"(hA1) : : "memory"); // behind: next words of A, headers and next words of B
+            gA.hd[0] = make_uint4(hA0.x, hA0.y, hA0.z, hA0.w);
+            gA.hd[1] = make_uint4(hA1.x, hA1.y, hA1.z, hA1.w);
+            if (!back_deferred(gA, i)) commit_zero(i);
+            else if (qn >= KID_CQ_FLUSH) resolve_all(i, 0xFFFFFFFFu);
+            seq = i + 2u;
+        }
+        // (the requests behind the last pair fetched words nobody needs; a fetch-and-add may still be out)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cA), "+v"(iA), "+v"(cB), "+v"(iB), "+v"(gv), "+v"(hB0), "+v"(hB1) : : "memory");
+        if (pendB) test_B(seq - 1u);
+        // a block of odd length ends the wave's work: seq counts its phantom, the flush below must not
+        if (nreal & 1u) seq -= 1u;
+        reads_done = seq;
+        if (qn) resolve_all(seq - 1u, 0xFFFFFFFFu);
+        if (seq & 63u) flush_results(seq & ~63u, seq & 63u);
+        else if (seq) flush_results(seq - 64u, 64u); // (a full last block: its in-loop flush would have come with the next trip)
+#else
         if (more) {
             issue_words(0u, cA, iA);
             issue_words(1u, cB, iB);
@@ -1422,6 +1658,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         reads_done = seq;
         if (qn) resolve_all(seq - 1u, 0xFFFFFFFFu);
         if (seq & 63u) flush_results(seq & ~63u, seq & 63u);
+#endif
 #ifdef KID_ENDHIST // development aid: when do the waves of a launch run out of reads?  24 bins of 64 us + a record per wave
         if (lane == 0) {
             const unsigned long long rel = __builtin_amdgcn_s_memrealtime() - rare->stats[30];
@@ -1954,6 +2191,33 @@ __global__ void kid_synth_reads_kernel(uint64_t db_seed, uint64_t read_seed, int
 
 // ------------------------------------------------------------------ random-gather ceiling
 // INF independent 16-byte loads per lane per round from uniformly random cells
+// The same question asked the way the classify kernel asks it: random 128-byte LINES of the table (cell 0 of a line),
+// RUN consecutive lanes on one line (1: 64 distinct lines per load; 8: what the headers of neighbouring k-mers look like),
+// four loads in flight per lane, issued from inline assembly and waited for once.
+template <int RUN, int MODE = 0> // MODE bit 0: a random cell of the line instead of cell 0; bit 1: the compiler's load and wait instead of inline assembly
+__global__ __launch_bounds__(256) void kid_gather_lines_kernel(const uint4 *table, uint32_t line_mask, uint64_t rounds, uint32_t *sink)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    uint32_t acc = 0;
+    uint64_t ctr = wave * 0x9E3779B97F4A7C15ULL + 12345;
+    for (uint64_t r = 0; r < rounds; r++) {
+        kid_u4 a[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            ctr += 0xD1B54A32D192ED03ULL;
+            const uint32_t line = (uint32_t)kid_fmix64(ctr ^ ((uint64_t)(lane / (uint32_t)RUN) << 48)) & line_mask;
+            const uint4 *p = table + (uint64_t)line * KID_LINE_CELLS + ((MODE & 1) ? (uint32_t)(ctr >> 40) & 7u : 0u);
+            if (MODE & 2) { const uint4 v = *p; a[u] = kid_u4{v.x, v.y, v.z, v.w}; }
+            else asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(a[u]) : "v"(p) : "memory");
+        }
+        if (!(MODE & 2)) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : : "memory");
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc ^= a[u].x ^ a[u].z;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 template <int INF>
 __global__ __launch_bounds__(256) void kid_gather_kernel(const uint4 *table, uint32_t slot_mask, uint64_t rounds, uint32_t *sink)
 {

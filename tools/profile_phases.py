@@ -38,4 +38,5 @@ v = list(out)[:9]
 tot = float(sum(v))
 for n, x in zip(names, v):
     print("%-16s %6.2f %%  %8.0f ticks/read" % (n, 100.0 * x / tot, x / (iters * n_reads)))
+print("resolver (contained in the phases above) %6.2f %%" % (100.0 * out[9] / tot))
 print("total ticks/read %.0f (s_memtime ticks; 100 MHz constant clock on gfx9+)" % (tot / (iters * n_reads)))
