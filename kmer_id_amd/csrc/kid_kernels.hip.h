@@ -33,6 +33,12 @@
 #define KID_ROW_WORDS 0 // pair kernel, 1: packed words by DPP row broadcasts instead of ds_bpermute (needs KID_WORDS_MASKED).
                         // Bit-exact and 16 LDS instructions per pair fewer, but not faster (profiles/r02/ab_row_words.txt): kept as a switch
 #endif
+#ifndef KID_BLOCK_CYCLIC
+#define KID_BLOCK_CYCLIC 1 // pair kernel: a wave's reads are whole blocks of 64 consecutive reads (0: read i of wave w = w + i x waves)
+#endif
+#ifndef KID_SEEN_POLICY
+#define KID_SEEN_POLICY "" // cache-policy bits of the seen-bitmap atomics (" sc1", " sc0 sc1", " nt": experiments)
+#endif
 #ifndef KID_SKEW
 #define KID_SKEW 0 // pair loop, 1: the second read's header test is taken in the next trip (see the loop); 0: straight order.
                    // Bit-exact, no faster (profiles/r02/ab_skew.txt: the loop is not bound by the wait for those headers)
@@ -96,7 +102,11 @@ __device__ __forceinline__ void kid_store_u32_nowait(uint32_t *p, uint32_t v)
 }
 __device__ __forceinline__ void kid_atomic_or_nowait(uint32_t *p, uint32_t v)
 {
-    asm volatile("global_atomic_or %0, %1, off" : : "v"(p), "v"(v) : "memory");
+#ifdef KID_ABLATE_SEEN_STORE // timing experiment only (wrong ucount): a plain byte store where the atomic is
+    asm volatile("global_store_byte %0, %1, off" : : "v"(p), "v"(v) : "memory");
+#else
+    asm volatile("global_atomic_or %0, %1, off" KID_SEEN_POLICY : : "v"(p), "v"(v) : "memory");
+#endif
 }
 
 __device__ __forceinline__ uint4 kid_load_cell(const uint4 *table, uint32_t idx) { return table[idx]; }
@@ -1005,8 +1015,12 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             }
             uint4 row = make_uint4(0, 0, 0, 0);
             if (tgt > 0) {
+#ifndef KID_ABLATE_NOFOLD // timing experiments only (wrong counters): what do the parts of hit handling cost?
                 if (ROWS) row = rare->rows[tgt];
+#endif
+#ifndef KID_ABLATE_NOSEEN
                 if (tgt > 1) kid_atomic_or_nowait(&rare->seen[slot >> 5], 1u << (slot & 31u));
+#endif
             }
             const uint64_t hitm = __ballot(tgt > 0);
             if (hitm && lane == 0) atomicAdd(&WC[2], (uint32_t)__popcll(hitm));
@@ -1031,7 +1045,12 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
                 }
             }
             if (ctag != 0xFFFFFFFFu && (uint32_t)__builtin_amdgcn_readfirstlane((int)tag) != ctag) commit_tag(ctag, final_t);
+#ifdef KID_ABLATE_NOFOLD
+            if (head) f = tgt;
+            if (false) {
+#else
             if (__popcll(hm) <= 6) {
+#endif
                 // Few, long runs (reads with many hits): the runs in turn, all entries of a run at once.
                 // Every lane works out the step its own entry would make from the run's current result;
                 // entries up to the first one that changes the result leave it as it is -- which is all
@@ -1069,7 +1088,11 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
                     if (lane == (uint32_t)h) { f = uf; fr = ufr; }
                 }
             } else
+#ifdef KID_ABLATE_NOFOLD
+            for (uint32_t t = 0; false; t++) {
+#else
             for (uint32_t t = 0; __ballot(head && t < len) != 0; t++) {
+#endif
                 const int src = (int)(((lane + t) & 63u) << 2);
                 const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)tgt);
                 uint4 rx;
@@ -1469,11 +1492,23 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
                 first = st;
                 stride = 1u;
             } else {
+#if KID_BLOCK_CYCLIC
+                // blocks of 64 CONSECUTIVE reads, dealt out wave by wave: the descriptors (1 KiB), packed words (2.4 KB)
+                // and results (256 bytes) of a block are lines that no other wave -- no other L2 -- touches.  With
+                // strided shares (read i of wave w = w + i x waves) every such line was shared by up to eight waves on
+                // as many XCDs, each of which missed on it in its own L2
+                const uint64_t f64 = ((uint64_t)gw32 + (uint64_t)sblk * nw32) * 64u;
+                sblk++;
+                first = f64 < n32 ? (uint32_t)f64 : n32;
+                stride = 1u;
+                len = n32 - first < 64u ? n32 - first : 64u;
+#else
                 const uint32_t j0 = sblk * 64u;
                 sblk++;
                 first = gw32 + j0 * nw32;
                 stride = nw32;
                 len = j0 < cnt ? (cnt - j0 < 64u ? cnt - j0 : 64u) : 0u;
+#endif
             }
             KidReadDesc d;
             d.first_base = 0; d.n_kmers = 0; d.pad = 0;
