@@ -1342,8 +1342,12 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             const uint32_t *const pc = b.codes + (w0 & 1023u);
             const uint16_t *const pi = b.inval + (w0 & 1023u);
 #else
-            const uint32_t *const pc = b.codes + w0;
-            const uint16_t *const pi = (hn >> 31) ? b.inval + w0 : b.inval; // clean read: any cached line will do, the mask is not looked at
+            const uint32_t *const pc0 = b.codes + w0;
+            const uint16_t *const pi0 = (hn >> 31) ? b.inval + w0 : b.inval; // clean read: any cached line will do, the mask is not looked at
+            // (said once more that these are wave-uniform: under register pressure hipcc has moved this address arithmetic
+            //  to the vector ALU and then handed the "s" operands below a VGPR pair -- a build error, seen once)
+            const uint32_t *const pc = reinterpret_cast<const uint32_t *>(uniform64((uint64_t)pc0));
+            const uint16_t *const pi = reinterpret_cast<const uint16_t *>(uniform64((uint64_t)pi0));
 #endif
 #if KID_WORDS_MASKED
             // A read of the pair kernel (<= 128 k-mers, k <= 32, behind a shift of <= 15 bases) lies in its first 12 packed
