@@ -1779,7 +1779,11 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
 
     // ---- flush (with the minimizer-localised table the histogram packs two 16-bit counters per word:
     // the host keeps a workgroup below 65536 reads per launch)
+#ifdef KID_ABLATE_NOFLUSH // timing experiment only (gcount stays empty): what do the histogram's global atomics cost?
+    if (false) {
+#else
     if (HIST) {
+#endif
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < hist_words; i += blockDim.x) {
             const uint32_t v = hist[i];
