@@ -39,6 +39,9 @@
 #ifndef KID_SEEN_POLICY
 #define KID_SEEN_POLICY "" // cache-policy bits of the seen-bitmap atomics (" sc1", " sc0 sc1", " nt": experiments)
 #endif
+#ifndef KID_SEEN_COMBINE
+#define KID_SEEN_COMBINE 1 // resolver: hits of a pass that fall into the same word of the seen bitmap share one atomic
+#endif
 #ifndef KID_SKEW
 #define KID_SKEW 0 // pair loop, 1: the second read's header test is taken in the next trip (see the loop); 0: straight order.
                    // Bit-exact, no faster (profiles/r02/ab_skew.txt: the loop is not bound by the wait for those headers)
@@ -1018,10 +1021,35 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
 #ifndef KID_ABLATE_NOFOLD // timing experiments only (wrong counters): what do the parts of hit handling cost?
                 if (ROWS) row = rare->rows[tgt];
 #endif
+            }
 #ifndef KID_ABLATE_NOSEEN
-                if (tgt > 1) kid_atomic_or_nowait(&rare->seen[slot >> 5], 1u << (slot & 31u));
+            {
+                // kmer_seen (:596-600).  The entries of a pass are in read and window order, and consecutive k-mers of a
+                // genome carry consecutive entry ordinals when the database lists them in genome order (the reference's
+                // builder does): the hits of a read then fall into two or three words of the bitmap.  Lanes that name the
+                // same word as a lane 1, 2, 4 or 8 places before them in their 16-lane row take that lane's bits along
+                // (bits of the same word, set by hits of this pass: OR-ing them in once more is harmless), and only the
+                // last lane of a run issues the atomic.  60 hits per read: 121 M atomics per 2 M reads became 1/16 of
+                // that; each one occupies an L2 channel for ~16 cycles (profiles/r02/ab_hitlog.txt).
+                const bool sb = tgt > 1;
+                const uint32_t word = sb ? slot >> 5 : 0xFFFFFFF0u + (lane & 15u); // (no two neighbours without a hit alike)
+                uint32_t bits = sb ? 1u << (slot & 31u) : 0u;
+#if KID_SEEN_COMBINE
+#define KID_SEEN_STEP(CTRL)                                                                                                    \
+                {                                                                                                               \
+                    const uint32_t w_ = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)word, CTRL, 0xF, 0xF, false); \
+                    const uint32_t b_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, CTRL, 0xF, 0xF, false);               \
+                    if (w_ == word) bits |= b_;                                                                                 \
+                }
+                KID_SEEN_STEP(0x111) KID_SEEN_STEP(0x112) KID_SEEN_STEP(0x114) KID_SEEN_STEP(0x118) // row_shr:1, 2, 4, 8
+#undef KID_SEEN_STEP
+                const uint32_t w_next = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)word, 0x101, 0xF, 0xF, false); // row_shl:1
+                if (sb && w_next != word) kid_atomic_or_nowait(&rare->seen[word], bits);
+#else
+                if (sb) kid_atomic_or_nowait(&rare->seen[word], bits);
 #endif
             }
+#endif
             const uint64_t hitm = __ballot(tgt > 0);
             if (hitm && lane == 0) atomicAdd(&WC[2], (uint32_t)__popcll(hitm));
             // Fold read by read, one lane per read: entries of a read are neighbours (a change of tag
