@@ -62,6 +62,9 @@
 // fingerprint false positive, a full line) are queued the old way.
 #define KID_EARLY_CAND 1
 #endif
+#ifndef KID_EARLY_MAX
+#define KID_EARLY_MAX 4u // ... for tiles with at most this many flagged lookups
+#endif
 #define KID_DYN_SHARDS 16u // counters the chunks are drawn from (one word takes ~90 fetches per microsecond)
 #ifndef KID_DYN_CHUNK
 #define KID_DYN_CHUNK 16u  // most reads a wave draws at a time (even)
@@ -1189,7 +1192,11 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
         for (int u = 0; u < U; u++) {
             const uint64_t qm = __ballot(mm[u]);
             if (qm == 0) continue;
-            const uint32_t cm = (KID_EARLY_CAND && mm[u]) ? kid_hdr_cand(g.hd[u], fp[u]) : 0u;
+            // (only while hits are sparse: with many flagged lookups per tile the resolver runs every few reads, finds the
+            //  lines still in the L2, and the wait for the candidate here would cost more than its second fetch --
+            //  builder-shaped database, 15.9 hits per read: 2.15 vs 1.92 ms per 1 M pairs, profiles/r02/clumped_ec.txt)
+            const bool early = KID_EARLY_CAND && (uint32_t)__popcll(qm) <= KID_EARLY_MAX && qn < 32u;
+            const uint32_t cm = (early && mm[u]) ? kid_hdr_cand(g.hd[u], fp[u]) : 0u;
             if (KID_EARLY_CAND) { // (cells read: one add for the wave)
                 const uint64_t cmb = __ballot(cm != 0);
                 if (cmb && lane == 0) atomicAdd(&WC[3], (uint32_t)__popcll(cmb));
