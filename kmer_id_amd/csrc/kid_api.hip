@@ -747,7 +747,10 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     const bool hist_pair = (hist_words16 + wpb * KID_PAIR_LDS_WORDS) * 4u + 32u <= 40u * 1024u;
     uint64_t span = b.n;
     if (ml && (hist || hist_pair)) {
-        const uint64_t cap = (uint64_t)grid * (65535u - 2u * (uint32_t)wpb); // reads per launch: < 65536 per workgroup
+        // reads per launch: < 65536 per workgroup -- and with the pair kernel's tapered shares (KID_TAPER) the workgroups
+        // dispatched first take up to 1.5 x the average (+ rounding to whole units per wave)
+        const uint64_t per_wg = KID_TAPER ? (uint64_t)(65535u - 2u * (uint32_t)wpb - 64u * (uint32_t)wpb) * (KID_TAPER + 1u) / (2u * KID_TAPER) : 65535u - 2u * (uint32_t)wpb;
+        const uint64_t cap = (uint64_t)grid * per_wg;
         if (span > cap) span = cap;
     }
     KidSampleDev sd{s->gcount, s->seen, s->stats};

@@ -42,6 +42,9 @@
 #ifndef KID_SEEN_COMBINE
 #define KID_SEEN_COMBINE 1 // resolver: hits of a pass that fall into the same word of the seen bitmap share one atomic
 #endif
+#ifndef KID_TAPER
+#define KID_TAPER 6u // pair kernel: the workgroups dispatched first take this many times the reads of those dispatched last (0: equal shares)
+#endif
 #ifndef KID_SKEW
 #define KID_SKEW 0 // pair loop, 1: the second read's header test is taken in the next trip (see the loop); 0: straight order.
                    // Bit-exact, no faster (profiles/r02/ab_skew.txt: the loop is not bound by the wait for those headers)
@@ -1536,11 +1539,30 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
                 // and results (256 bytes) of a block are lines that no other wave -- no other L2 -- touches.  With
                 // strided shares (read i of wave w = w + i x waves) every such line was shared by up to eight waves on
                 // as many XCDs, each of which missed on it in its own L2
+#if KID_TAPER
+                // ... in shares that shrink: the first half of the workgroups (dispatched first) take KID_TAPER units of reads
+                // per wave, the second half one.  Workgroups take 200-330 us for the same number of reads, and a launch
+                // ends when the slowest of its last workgroups does: with equal shares the chip idles through half the
+                // spread of a 250-us workgroup at the end of a 1-ms launch, with small last shares through a third of that.
+                const uint32_t G = gridDim.x, half = G >> 1, wg = blockIdx.x;
+                const uint32_t units = wpb * (KID_TAPER * half + (G - half));    // shares of one unit per wave
+                const uint32_t unit = (((n32 + units - 1u) / units) + 1u) & ~1u; // reads per unit (even)
+                const uint32_t mine = wg < half ? KID_TAPER : 1u;
+                const uint64_t ufirst = (uint64_t)wpb * (wg < half ? KID_TAPER * wg : KID_TAPER * half + (wg - half)) + (uint64_t)wib * mine;
+                const uint64_t wave_first = ufirst * unit, off = (uint64_t)sblk * 64u, wave_cnt = (uint64_t)mine * unit;
+                sblk++;
+                const uint64_t f64 = wave_first + off;
+                first = f64 < n32 ? (uint32_t)f64 : n32;
+                stride = 1u;
+                len = off < wave_cnt ? (uint32_t)(wave_cnt - off < 64u ? wave_cnt - off : 64u) : 0u;
+                if (len > n32 - first) len = n32 - first;
+#else
                 const uint64_t f64 = ((uint64_t)gw32 + (uint64_t)sblk * nw32) * 64u;
                 sblk++;
                 first = f64 < n32 ? (uint32_t)f64 : n32;
                 stride = 1u;
                 len = n32 - first < 64u ? n32 - first : 64u;
+#endif
 #else
                 const uint32_t j0 = sblk * 64u;
                 sblk++;
@@ -1738,11 +1760,13 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             const unsigned long long rel = __builtin_amdgcn_s_memrealtime() - rare->stats[30];
             const unsigned long long bin = rel / 6400ull;
             atomicAdd(&rare->stats[8 + (bin < 23ull ? bin : 23ull)], 1ull);
-            uint32_t *rec = rare->dyn + KID_DYN_SHARDS * 16u + 4u * (uint32_t)gw;
-            rec[0] = seq;                 // reads classified
-            rec[1] = (uint32_t)rel;       // end of its loop, 10 ns ticks from the launch's first workgroup start
-            rec[2] = eh_last;             // start of its last block
-            rec[3] = eh_nblk;             // blocks drawn
+            if (gw < 16384u) { // (the record area holds 16384 waves: kid_api.hip; a grid of 16 workgroups per CU has 32768)
+                uint32_t *rec = rare->dyn + KID_DYN_SHARDS * 16u + 4u * (uint32_t)gw;
+                rec[0] = seq;                 // reads classified
+                rec[1] = (uint32_t)rel;       // end of its loop, 10 ns ticks from the launch's first workgroup start
+                rec[2] = eh_last;             // start of its last block
+                rec[3] = eh_nblk;             // blocks drawn
+            }
         }
 #endif
 #ifdef KID_WAVEPROF
