@@ -931,13 +931,14 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
     // with the loads, and the explicit counts of the loop would have to sit out its acknowledgement
     uint32_t *const RB = CQ_lw + KID_CQ_CAP + KID_CQ_CAP / 4;
     const uint32_t gw32 = (uint32_t)gw, nw32 = (uint32_t)nw; // 32-bit read indices (n < 2^31): read number i of this wave is gw + i nw
+    uint32_t rd_first = gw32, rd_stride = nw32; // ... except in the duo kernel: a contiguous range (set below), rd_first + i
     uint64_t rb_skip = 0;   // result slots of the current block of 64 reads that are not this pass's to store
     bool rb_direct = false; // second pass of the general loops (reads of more than one segment): results stored at once
     uint32_t *const RG = RB + 64; // pair kernel: which read of the batch a result slot belongs to (128 slots: the next block's are known early)
     auto flush_results = [&](const uint32_t i0, const uint32_t n) { // this wave's reads i0 .. i0+n-1 (n <= 64)
         uint32_t *const outp = rare->out_final;
         if (outp && lane < n && !((rb_skip >> ((i0 + lane) & 63u)) & 1ull))
-            kid_store_u32_nowait(&outp[PAIRK == 1 ? RG[(i0 + lane) & 127u] : gw32 + (i0 + lane) * nw32], RB[(i0 + lane) & 63u]);
+            kid_store_u32_nowait(&outp[PAIRK == 1 ? RG[(i0 + lane) & 127u] : rd_first + (i0 + lane) * rd_stride], RB[(i0 + lane) & 63u]);
         rb_skip = 0;
         RB[lane] = 0; // (a read without any hit does not write its slot: see commit_zero)
     };
@@ -1351,7 +1352,26 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
     // return in order, and anything the compiler issues in between (hit cells, atomics, the out_final
     // store) only makes an explicit count stricter than needed.
     if constexpr (PAIRK != 0) {
-        const uint32_t cnt = gw < b.n ? (uint32_t)((b.n - gw + nw - 1) / nw) : 0u; // reads of this wave: gw + i nw
+        uint32_t cnt = gw < b.n ? (uint32_t)((b.n - gw + nw - 1) / nw) : 0u; // reads of this wave: gw + i nw
+        uint32_t duo_first = gw32, duo_stride = nw32;
+#if KID_TAPER
+        if (PAIRK == 2) {
+            // the duo kernel's waves take one contiguous range of reads each, in the pair kernel's shrinking shares (see
+            // switch_block): KID_TAPER units of reads per wave in the first half of the workgroups, one in the second
+            const uint32_t nb2 = (uint32_t)b.n, G = gridDim.x, half = G >> 1, wg = blockIdx.x;
+            const uint32_t units = wpb * (KID_TAPER * half + (G - half));
+            const uint32_t unit = (nb2 + units - 1u) / units;
+            const uint32_t mine = wg < half ? KID_TAPER : 1u;
+            const uint64_t ufirst = (uint64_t)wpb * (wg < half ? KID_TAPER * wg : KID_TAPER * half + (wg - half)) + (uint64_t)wib * mine;
+            const uint64_t f64 = ufirst * unit;
+            duo_first = f64 < nb2 ? (uint32_t)f64 : nb2;
+            duo_stride = 1u;
+            cnt = nb2 - duo_first < mine * unit ? nb2 - duo_first : mine * unit;
+            rd_first = duo_first;
+            rd_stride = 1u;
+            reads_done = cnt;
+        }
+#endif
         const uint32_t lane4 = lane * 4u;
         const uint32_t lane4row = ((lane >> 4) + (lane & 15u)) * 4u; // byte offset of the word a lane holds when words come row-wise
         // descriptors, 64 at a time: lane l holds the one of read number blk + l of this wave -- the low word
@@ -1361,7 +1381,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
         // has the wave-local number seg_seq0 + j (tags and result slots go by wave-local numbers, which simply run on
         // from segment to segment).  The duo kernel has one segment: the wave's strided share of the batch.
         uint32_t blk = 0, dv_lo = 0, dv_hn = 0;
-        uint32_t seg_first = gw32, seg_stride = nw32, seg_seq0 = 0, seg_end = cnt;
+        uint32_t seg_first = duo_first, seg_stride = duo_stride, seg_seq0 = 0, seg_end = cnt;
         auto load_block = [&]() {
             const uint32_t sq = blk + lane; // wave-local number
             dv_lo = 0; dv_hn = 0;
