@@ -931,7 +931,8 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
     // with the loads, and the explicit counts of the loop would have to sit out its acknowledgement
     uint32_t *const RB = CQ_lw + KID_CQ_CAP + KID_CQ_CAP / 4;
     const uint32_t gw32 = (uint32_t)gw, nw32 = (uint32_t)nw; // 32-bit read indices (n < 2^31): read number i of this wave is gw + i nw
-    uint32_t rd_first = gw32, rd_stride = nw32; // ... except in the duo kernel: a contiguous range (set below), rd_first + i
+    uint32_t rd_first = gw32, rd_stride = nw32; // ... except where a wave takes a contiguous range (set below): rd_first + i
+    uint32_t gen_cnt = 0;                         // general loops: reads of this wave
     uint64_t rb_skip = 0;   // result slots of the current block of 64 reads that are not this pass's to store
     bool rb_direct = false; // second pass of the general loops (reads of more than one segment): results stored at once
     uint32_t *const RG = RB + 64; // pair kernel: which read of the batch a result slot belongs to (128 slots: the next block's are known early)
@@ -958,14 +959,14 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             pend_t = final_t;
             pend_n = 1;
         }
-        if (rb_direct) { if (lane == 0 && b.out_final) kid_store_u32_nowait(&b.out_final[gw32 + i * nw32], final_t); }
+        if (rb_direct) { if (lane == 0 && b.out_final) kid_store_u32_nowait(&b.out_final[rd_first + i * rd_stride], final_t); }
         else if (lane == 0) RB[i & 63u] = final_t;
     };
     // the common case, a read without a single candidate: counted in a scalar register, its result slot is
     // zero already
     auto commit_zero = [&](const uint32_t i) {
         n_zero++;
-        if (rb_direct && lane == 0 && b.out_final) kid_store_u32_nowait(&b.out_final[gw32 + i * nw32], 0u);
+        if (rb_direct && lane == 0 && b.out_final) kid_store_u32_nowait(&b.out_final[rd_first + i * rd_stride], 0u);
     };
     // i_now: number of the newest queued read (all are within 63 of it); open_tag: a read that may still get
     // entries (general loops, between the groups of a read) -- its run is folded but not committed
@@ -1156,7 +1157,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             if (head && (lane != last || !more_chunks)) {
                 if (HIST) atomicAdd(&hist[f >> 1], 1u << (16u * (f & 1u)));
                 else atomicAdd(&rare->gcount[f], 1ull);
-                if (rb_direct) { if (b.out_final) kid_store_u32_nowait(&b.out_final[gw32 + (i_now - ((i_now - tag) & 63u)) * nw32], f); }
+                if (rb_direct) { if (b.out_final) kid_store_u32_nowait(&b.out_final[rd_first + (i_now - ((i_now - tag) & 63u)) * rd_stride], f); }
                 else RB[tag] = f; // tag = read number mod 64
             }
             if (more_chunks) {
@@ -1812,25 +1813,43 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
         // and its first packed words one read ahead; the waits the compiler places in front of their
         // first use land behind a whole read's worth of work.  32-bit read indices (n < 2^31).
         const uint32_t n32 = (uint32_t)b.n;
+        // the wave's reads: rd_first + i rd_stride, i < gen_cnt -- a strided share of the batch, or (KID_TAPER, minimizer-
+        // localised table) one contiguous range in the pair kernel's shrinking shares
+        gen_cnt = gw32 < n32 ? (n32 - gw32 + nw32 - 1u) / nw32 : 0u;
+#if KID_TAPER
+        if (MINLOC) {
+            const uint32_t G = gridDim.x, half = G >> 1, wg = blockIdx.x;
+            const uint32_t units = wpb * (KID_TAPER * half + (G - half));
+            const uint32_t unit = (n32 + units - 1u) / units;
+            const uint32_t mine = wg < half ? KID_TAPER : 1u;
+            const uint64_t ufirst = (uint64_t)wpb * (wg < half ? KID_TAPER * wg : KID_TAPER * half + (wg - half)) + (uint64_t)wib * mine;
+            const uint64_t f64 = ufirst * unit;
+            rd_first = f64 < n32 ? (uint32_t)f64 : n32;
+            rd_stride = 1u;
+            gen_cnt = n32 - rd_first < mine * unit ? n32 - rd_first : mine * unit;
+            reads_done = gen_cnt;
+        }
+#endif
+        const uint32_t gf = rd_first, gs = rd_stride, gc = gen_cnt;
         KidReadDesc dA, dB;
         uint32_t cA, iA, cB, iB;
-        fetch_desc(gw32, dA);
-        fetch_desc(gw32 + nw32, dB);
+        fetch_desc(gc > 0u ? gf : n32, dA);
+        fetch_desc(gc > 1u ? gf + gs : n32, dB);
         fetch_words(dA, cA, iA);
-        uint32_t i = 0; // number of the read within this wave
-        for (uint32_t r = gw32; r < n32; r += 2 * nw32, i += 2) {
+        for (uint32_t i = 0; i < gc; i += 2) { // i: number of the read within this wave
+            const uint32_t r = gf + i * gs;
             short_read(r, i, uniform64(dA.first_base), __builtin_amdgcn_readfirstlane(dA.n_kmers), cA, iA,
-                       [&]() { fetch_words(dB, cB, iB); fetch_desc(r + 2 * nw32, dA); });
-            if (r + nw32 >= n32) break;
-            short_read(r + nw32, i + 1u, uniform64(dB.first_base), __builtin_amdgcn_readfirstlane(dB.n_kmers), cB, iB,
-                       [&]() { fetch_words(dA, cA, iA); fetch_desc(r + 3 * nw32, dB); });
+                       [&]() { fetch_words(dB, cB, iB); fetch_desc(i + 2u < gc ? r + 2u * gs : n32, dA); });
+            if (i + 1u >= gc) break;
+            short_read(r + gs, i + 1u, uniform64(dB.first_base), __builtin_amdgcn_readfirstlane(dB.n_kmers), cB, iB,
+                       [&]() { fetch_words(dA, cA, iA); fetch_desc(i + 3u < gc ? r + 3u * gs : n32, dB); });
             if (MINLOC && ((i + 2u) & 63u) == 0u) { // tags and result slots are read numbers mod 64
                 if (qn || cur_tag != 0xFFFFFFFFu) resolve_all(i + 1u, 0xFFFFFFFFu);
                 flush_results(i + 2u - 64u, 64u);
             }
         }
         if (MINLOC) {
-            const uint32_t cnt = gw < b.n ? (uint32_t)((b.n - gw + nw - 1) / nw) : 0u;
+            const uint32_t cnt = gc;
             if (qn || cur_tag != 0xFFFFFFFFu) resolve_all(cnt - 1u, 0xFFFFFFFFu);
             if (cnt & 63u) flush_results(cnt & ~63u, cnt & 63u);
         }
@@ -1838,8 +1857,8 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
     // ---- phase 2: the long reads this wave met (FASTA records, long-read data), one at a time
     if (PAIRK == 0 && any_long) {
         rb_direct = true; // the other reads' results are stored already: these go out one by one
-        uint32_t i = 0;
-        for (uint64_t r = gw; r < b.n; r += nw, i++) {
+        for (uint32_t i = 0; i < gen_cnt; i++) {
+            const uint64_t r = (uint64_t)rd_first + (uint64_t)i * rd_stride;
             const KidReadDesc d = descs[r];
             const int64_t nk = (int64_t)__builtin_amdgcn_readfirstlane(d.n_kmers);
             if (nk <= KID_SEG_KMERS) continue;
