@@ -750,7 +750,8 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
         // reads per launch: < 65536 per workgroup -- and with the pair kernel's tapered shares (KID_TAPER) the workgroups
         // dispatched first take up to 1.5 x the average (+ rounding to whole units per wave)
         const uint64_t per_wg = KID_TAPER ? (uint64_t)(65535u - 2u * (uint32_t)wpb - 64u * (uint32_t)wpb) * (KID_TAPER + 1u) / (2u * KID_TAPER) : 65535u - 2u * (uint32_t)wpb;
-        const uint64_t cap = (uint64_t)grid * per_wg;
+        // (the bound assumes the two halves of the grid are equal: an odd grid -- only ever a small one -- gets half of it)
+        const uint64_t cap = (uint64_t)grid * ((KID_TAPER && (grid & 1)) ? per_wg / 2 : per_wg);
         if (span > cap) span = cap;
     }
     KidSampleDev sd{s->gcount, s->seen, s->stats};
