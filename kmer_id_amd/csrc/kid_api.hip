@@ -102,7 +102,8 @@ struct kid_sample {
         uint64_t chunks_cap = 0;
         KidRareArgs *rare = nullptr;  // device copy, written in kid_sample_begin (per batch: batch_max, desc, out_final)
         hipEvent_t ev_prep = nullptr; // pack + prepare of the batch using the set are done
-        hipEvent_t ev_used = nullptr; // ... its classify kernels are done: the set may be overwritten
+        hipEvent_t ev_used = nullptr; // ... its classify kernels are done: the set may be overwritten (recorded when a pack on another stream asks)
+        hipStream_t used_stream = nullptr; // the stream those classify kernels were queued on
         bool used = false;
     };
     static const int NSET = 3;
@@ -717,8 +718,17 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
         KID_HIP(hipMalloc(&sc.inval, (nchunks + 64) * 2));
         sc.chunks_cap = nchunks;
     }
-    // the batch that used this set three batches ago must be through its classify kernels before the set is overwritten
-    if (sc.used) KID_HIP(hipStreamWaitEvent(prep_stream, sc.ev_used, 0));
+    // The batch that used this set three batches ago must be through its classify kernels before the set is overwritten.
+    // On the stream those kernels ran on that is a matter of stream order; only a different pack stream needs an event --
+    // recorded now, behind everything queued on that stream so far (an event per batch, recorded and waited for, kept the
+    // GPU idle for ~10 us of every 1.1-ms step).
+    if (sc.used && sc.used_stream != prep_stream) {
+        if (hipEventRecord(sc.ev_used, sc.used_stream) == hipSuccess) KID_HIP(hipStreamWaitEvent(prep_stream, sc.ev_used, 0));
+        else { // (a caller's stream that is gone by now: everything queued on it has run or the device is in error)
+            (void)hipGetLastError();
+            KID_HIP(hipDeviceSynchronize());
+        }
+    }
     if (nchunks)
         hipLaunchKernelGGL(kid_pack_kernel, dim3(kid_grid_for(nchunks, 256, db->num_cu * 16)), dim3(256), 0, prep_stream, b.bases,
                            nchunks, db->d.u_is_t, sc.codes, sc.inval);
@@ -850,7 +860,7 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
         s->timed.emplace_back(ev0.release(), ev1.release());
         s->timed_batches++;
     }
-    KID_HIP(hipEventRecord(sc.ev_used, stream));
+    sc.used_stream = stream;
     sc.used = true;
     KID_HIP(hipGetLastError());
     s->reads_submitted += b.n;
