@@ -733,7 +733,8 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
         hipLaunchKernelGGL(kid_pack_kernel, dim3(kid_grid_for(nchunks, 256, db->num_cu * 16)), dim3(256), 0, prep_stream, b.bases,
                            nchunks, db->d.u_is_t, sc.codes, sc.inval);
     hipLaunchKernelGGL(kid_prepare_kernel, dim3(kid_grid_for(b.n, 256, db->num_cu * 8)), dim3(256), 0, prep_stream, b, db->info.k,
-                       sc.desc, s->stats, sc.rare, ++s->batch_seq, nchunks ? sc.inval : nullptr, plan ? plan->cut : 0u);
+                       sc.desc, s->stats, sc.rare, ++s->batch_seq, nchunks ? sc.inval : nullptr, plan ? plan->cut : 0u,
+                       prep_stream == stream ? 1 : 0);
     if (prep_stream != stream) {
         KID_HIP(hipEventRecord(sc.ev_prep, prep_stream));
         KID_HIP(hipStreamWaitEvent(stream, sc.ev_prep, 0));
@@ -777,7 +778,8 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     KidPacked pk{sc.codes, sc.inval, sc.desc + r0, b.out_final ? b.out_final + r0 : nullptr, cnt};
     // the kernels find this launch's descriptors and result array in the set's device argument block; the first launch
     // of a batch also banks / arms the device-clock stamps (here, in classify-stream order: prepare may run early)
-    hipLaunchKernelGGL(kid_rebase_kernel, dim3(1), dim3(64), 0, stream, sc.rare, pk.desc, pk.out_final, s->stats, r0 == 0 ? 1 : 0);
+    if (r0 != 0 || prep_stream != stream) // (the first launch of a batch prepared on this stream: done by kid_prepare_kernel)
+        hipLaunchKernelGGL(kid_rebase_kernel, dim3(1), dim3(64), 0, stream, sc.rare, pk.desc, pk.out_final, s->stats, r0 == 0 ? 1 : 0);
 #define KID_LAUNCH1(R, H, M, KF, PK)                                                                                            \
     hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, KF, PK>), dim3(grid), dim3(block),                                     \
                        (((H) ? ((PK) ? hist_words16 : hist_words) : 0u) +                                                       \

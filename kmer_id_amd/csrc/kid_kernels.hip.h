@@ -414,11 +414,31 @@ __device__ __forceinline__ void kid_pack16(const uint4 v, const uint32_t u_is_t,
 // ------------------------------------------------------------------ batch preparation
 // [start, stop] -> descriptor; the range checks the reference leaves to string::at() happen here
 // (runs after kid_pack_kernel: `inval` is the packed invalid-mask image of the batch)
-__global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, unsigned long long *stats, KidRareArgs *rare, uint32_t seq,
-                                   const uint16_t *inval, uint32_t long_cut)
+// what a launch of the classify kernels finds in the set's device argument block: its share of the descriptors and of the
+// result array; `arm`: the device-clock bracket of the batch (kid_sample_kernel_time_device) -- bank the interval of the
+// batch before, arm the slots for this one.  stats[30] = first start, stats[31] = last end (100 MHz ticks)
+__device__ __forceinline__ void kid_rebase(KidRareArgs *rare, const KidReadDesc *desc, uint32_t *out_final, unsigned long long *stats, int arm)
 {
-    // (descriptor / result pointers, the chunk counters and the device-clock stamps of the batch are set by
-    //  kid_rebase_kernel in classify-stream order: this kernel may run while the batch before is being classified)
+    if (threadIdx.x == 0) {
+        rare->desc = desc;
+        rare->out_final = out_final;
+        if (arm) {
+            const unsigned long long a = stats[30], z = stats[31];
+            if (z > a) { stats[6] += z - a; stats[7] += 1; }
+            stats[30] = ~0ull;
+            stats[31] = 0;
+        }
+    }
+    if (threadIdx.x < KID_DYN_SHARDS) rare->dyn[threadIdx.x * 16u] = 0;
+}
+
+__global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, unsigned long long *stats, KidRareArgs *rare, uint32_t seq,
+                                   const uint16_t *inval, uint32_t long_cut, int rebase)
+{
+    // (descriptor / result pointers, the chunk counters and the device-clock stamps of the batch are set in classify-stream
+    //  order: by kid_rebase_kernel when this kernel may run while the batch before is being classified, else -- `rebase`,
+    //  same stream -- right here for the batch's first launch: one launch and its gap less per step)
+    if (rebase && blockIdx.x == 0) kid_rebase(rare, desc, b.out_final, stats, 1);
     uint32_t bad = 0, mx = 0;
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < b.n; r += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t off;
@@ -474,19 +494,7 @@ __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, u
 // a batch classified in several launches: the next launch's share of the descriptors and of the result array
 __global__ void kid_rebase_kernel(KidRareArgs *rare, const KidReadDesc *desc, uint32_t *out_final, unsigned long long *stats, int arm)
 {
-    if (threadIdx.x == 0) {
-        rare->desc = desc;
-        rare->out_final = out_final;
-        if (arm) {
-            // device-clock bracket of the classify kernels (kid_sample_kernel_time_device): bank the interval of the batch
-            // before, arm the slots for this one.  stats[30] = first start, stats[31] = last end (100 MHz ticks)
-            const unsigned long long a = stats[30], z = stats[31];
-            if (z > a) { stats[6] += z - a; stats[7] += 1; }
-            stats[30] = ~0ull;
-            stats[31] = 0;
-        }
-    }
-    if (threadIdx.x < KID_DYN_SHARDS) rare->dyn[threadIdx.x * 16u] = 0;
+    kid_rebase(rare, desc, out_final, stats, arm);
 }
 
 // ASCII -> 2 bits per base + invalid mask for the whole batch buffer, 16 bases per lane
