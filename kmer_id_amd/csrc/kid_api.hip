@@ -104,6 +104,7 @@ struct kid_sample {
         hipEvent_t ev_prep = nullptr; // pack + prepare of the batch using the set are done
         hipEvent_t ev_used = nullptr; // ... its classify kernels are done: the set may be overwritten (recorded when a pack on another stream asks)
         hipStream_t used_stream = nullptr; // the stream those classify kernels were queued on
+        bool used_recorded = false;        // ev_used was recorded right behind them
         bool used = false;
     };
     static const int NSET = 3;
@@ -723,18 +724,21 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     // recorded now, behind everything queued on that stream so far (an event per batch, recorded and waited for, kept the
     // GPU idle for ~10 us of every 1.1-ms step).
     if (sc.used && sc.used_stream != prep_stream) {
-        if (hipEventRecord(sc.ev_used, sc.used_stream) == hipSuccess) KID_HIP(hipStreamWaitEvent(prep_stream, sc.ev_used, 0));
+        // (recorded behind the set's classify kernels when those ran beside a pack stream -- the host path; else now,
+        //  behind everything queued on that stream so far)
+        if (sc.used_recorded || hipEventRecord(sc.ev_used, sc.used_stream) == hipSuccess) KID_HIP(hipStreamWaitEvent(prep_stream, sc.ev_used, 0));
         else { // (a caller's stream that is gone by now: everything queued on it has run or the device is in error)
             (void)hipGetLastError();
             KID_HIP(hipDeviceSynchronize());
         }
     }
+    const bool fuse_rebase = prep_stream == stream;
     if (nchunks)
         hipLaunchKernelGGL(kid_pack_kernel, dim3(kid_grid_for(nchunks, 256, db->num_cu * 16)), dim3(256), 0, prep_stream, b.bases,
                            nchunks, db->d.u_is_t, sc.codes, sc.inval);
     hipLaunchKernelGGL(kid_prepare_kernel, dim3(kid_grid_for(b.n, 256, db->num_cu * 8)), dim3(256), 0, prep_stream, b, db->info.k,
                        sc.desc, s->stats, sc.rare, ++s->batch_seq, nchunks ? sc.inval : nullptr, plan ? plan->cut : 0u,
-                       prep_stream == stream ? 1 : 0);
+                       fuse_rebase ? 1 : 0);
     if (prep_stream != stream) {
         KID_HIP(hipEventRecord(sc.ev_prep, prep_stream));
         KID_HIP(hipStreamWaitEvent(stream, sc.ev_prep, 0));
@@ -778,7 +782,7 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     KidPacked pk{sc.codes, sc.inval, sc.desc + r0, b.out_final ? b.out_final + r0 : nullptr, cnt};
     // the kernels find this launch's descriptors and result array in the set's device argument block; the first launch
     // of a batch also banks / arms the device-clock stamps (here, in classify-stream order: prepare may run early)
-    if (r0 != 0 || prep_stream != stream) // (the first launch of a batch prepared on this stream: done by kid_prepare_kernel)
+    if (r0 != 0 || !fuse_rebase) // (the first launch of a batch prepared on this stream: done by kid_prepare_kernel)
         hipLaunchKernelGGL(kid_rebase_kernel, dim3(1), dim3(64), 0, stream, sc.rare, pk.desc, pk.out_final, s->stats, r0 == 0 ? 1 : 0);
 #define KID_LAUNCH1(R, H, M, KF, PK)                                                                                            \
     hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, KF, PK>), dim3(grid), dim3(block),                                     \
@@ -862,6 +866,11 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
         s->timed.emplace_back(ev0.release(), ev1.release());
         s->timed_batches++;
     }
+    // pack and prepare on a stream of their own (the host path: they run beside the classify kernels of the batch before):
+    // the pack that overwrites this set three batches on waits for exactly these kernels, not for whatever the classify
+    // stream holds by then (148 instead of 153 M pairs/s from host buffers, profiles/r02/ab_lazy_event.txt)
+    sc.used_recorded = prep_stream != stream;
+    if (sc.used_recorded) KID_HIP(hipEventRecord(sc.ev_used, stream));
     sc.used_stream = stream;
     sc.used = true;
     KID_HIP(hipGetLastError());
