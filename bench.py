@@ -37,8 +37,10 @@ K = 30
 READ_LEN = 150
 # BASELINE.json configs: [1] 1 M pairs per step (the configuration the metric is quoted on), [2] 100 M pairs in one
 # sample (the roofline run): one step = one batch = kid_classify_fixed_device over the whole resident read set
-CONFIGS = {"1m": {"pairs": 1_000_000, "steps": 10, "warmup": 2, "batches": 4},
-           "roofline100m": {"pairs": 100_000_000, "steps": 2, "warmup": 1, "batches": 1}}
+# (steps / warmup: a step is ~1.1 ms; the first tens of steps after the database build run 5-9 % slower -- clocks and
+#  translation caches settle -- so the default warms up for 50 steps and times 200: profiles/r02/ab_warmup.txt)
+CONFIGS = {"1m": {"pairs": 1_000_000, "steps": 200, "warmup": 50, "batches": 4},
+           "roofline100m": {"pairs": 100_000_000, "steps": 4, "warmup": 2, "batches": 1}}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
