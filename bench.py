@@ -328,32 +328,8 @@ def main():
         sample.classify_fixed_device(batches[i % nb].data_ptr(), READ_LEN, n_reads, d_out=out_final.data_ptr(),
                                      stream=stream.cuda_stream)
 
-    # full-size cross-check (untimed): the same batch through a table with the reference's cell
-    # placement must give the same per-read targets and counters; its probe count is the
-    # "algorithmic" number of cells the reference's own table would have read.
     xcheck = None
     ref_probes_per_lookup = None
-    if want_x:
-        d_keys, d_targets, n_keys = dev_keys
-        rdb = KmerDB.from_device(d_keys.data_ptr(), d_targets.data_ptr(), n_keys, parent, k=K, log2_slots=args.log2_slots,
-                                 flags=kmer_id_amd.KID_FLAG_REF_GEOMETRY, device=device.index)
-        del d_keys, d_targets, dev_keys
-        rs = rdb.sample()
-        out_ref = torch.empty(n_reads, dtype=torch.int32, device=device)
-        rs.classify_fixed_device(batches[0].data_ptr(), READ_LEN, n_reads, d_out=out_ref.data_ptr(), stream=stream.cuda_stream)
-        step(0)
-        torch.cuda.synchronize(device)
-        g1, u1 = sample.end()
-        g2, u2 = rs.end()
-        st_ref = rs.stats()
-        xcheck = bool(torch.equal(out_ref, out_final) and np.array_equal(g1, g2) and np.array_equal(u1, u2))
-        ref_probes_per_lookup = st_ref["probes"] / max(st_ref["lookups"], 1)
-        log("cross-check vs reference geometry on %d reads: %s (reference geometry reads %.4f cells per lookup)" % (
-            n_reads, "identical" if xcheck else "MISMATCH", ref_probes_per_lookup))
-        rs.close(); rdb.close(); del out_ref
-        torch.cuda.empty_cache()
-        if not xcheck:
-            raise SystemExit("minimizer-localised and reference geometries disagree")
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(device)
@@ -395,6 +371,32 @@ def main():
     assert total_reads == args.steps * n_reads, (total_reads, args.steps * n_reads)
     if os.environ.get("KID_BENCH_ABLATION") != "1":  # (timing experiments with builds whose counters are wrong on purpose)
         assert int(g.sum()) == args.steps * n_reads * world, "gcount does not add up to the reads processed"
+    # full-size cross-check (untimed, AFTER the timed region: freeing its 16 GiB table sets the driver wiping VRAM, which
+    # took 5-10 % out of the steps that followed when the check ran first): the same batch through a table with the
+    # reference's cell placement must give the same per-read targets and counters; its probe count is the "algorithmic"
+    # number of cells the reference's own table would have read.
+    if want_x:
+        d_keys, d_targets, n_keys = dev_keys
+        rdb = KmerDB.from_device(d_keys.data_ptr(), d_targets.data_ptr(), n_keys, parent, k=K, log2_slots=args.log2_slots,
+                                 flags=kmer_id_amd.KID_FLAG_REF_GEOMETRY, device=device.index)
+        del d_keys, d_targets, dev_keys
+        rs = rdb.sample()
+        xs = db.sample()
+        out_ref = torch.empty(n_reads, dtype=torch.int32, device=device)
+        rs.classify_fixed_device(batches[0].data_ptr(), READ_LEN, n_reads, d_out=out_ref.data_ptr(), stream=stream.cuda_stream)
+        xs.classify_fixed_device(batches[0].data_ptr(), READ_LEN, n_reads, d_out=out_final.data_ptr(), stream=stream.cuda_stream)
+        torch.cuda.synchronize(device)
+        g1, u1 = xs.end()
+        g2, u2 = rs.end()
+        st_ref = rs.stats()
+        xcheck = bool(torch.equal(out_ref, out_final) and np.array_equal(g1, g2) and np.array_equal(u1, u2))
+        ref_probes_per_lookup = st_ref["probes"] / max(st_ref["lookups"], 1)
+        log("cross-check vs reference geometry on %d reads: %s (reference geometry reads %.4f cells per lookup)" % (
+            n_reads, "identical" if xcheck else "MISMATCH", ref_probes_per_lookup))
+        rs.close(); xs.close(); rdb.close(); del out_ref
+        torch.cuda.empty_cache()
+        if not xcheck:
+            raise SystemExit("minimizer-localised and reference geometries disagree")
     kern_s = sum(kernel_ms) / 1e3
     # algorithmic bytes: 16 B per table cell the REFERENCE's table geometry reads for
     # these lookups (counted exactly on the reference-geometry table above), whatever our own
