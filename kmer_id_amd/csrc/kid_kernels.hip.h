@@ -68,6 +68,9 @@
 #ifndef KID_EARLY_MAX
 #define KID_EARLY_MAX 4u // ... for tiles with at most this many flagged lookups
 #endif
+#ifndef KID_EARLY_QN
+#define KID_EARLY_QN 32u // ... while fewer than this many lookups are queued
+#endif
 #define KID_DYN_SHARDS 16u // counters the chunks are drawn from (one word takes ~90 fetches per microsecond)
 #ifndef KID_DYN_CHUNK
 #define KID_DYN_CHUNK 16u  // most reads a wave draws at a time (even)
@@ -1208,7 +1211,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             // (only while hits are sparse: with many flagged lookups per tile the resolver runs every few reads, finds the
             //  lines still in the L2, and the wait for the candidate here would cost more than its second fetch --
             //  builder-shaped database, 15.9 hits per read: 2.15 vs 1.92 ms per 1 M pairs, profiles/r02/clumped_ec.txt)
-            const bool early = KID_EARLY_CAND && (uint32_t)__popcll(qm) <= KID_EARLY_MAX && qn < 32u;
+            const bool early = KID_EARLY_CAND && (uint32_t)__popcll(qm) <= KID_EARLY_MAX && qn < KID_EARLY_QN;
             const uint32_t cm = (early && mm[u]) ? kid_hdr_cand(g.hd[u], fp[u]) : 0u;
             if (KID_EARLY_CAND) { // (cells read: one add for the wave)
                 const uint64_t cmb = __ballot(cm != 0);
