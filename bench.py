@@ -14,6 +14,11 @@ sample is closed inside the timed region: ucount from the seen-bitmap and, for
 N > 1, the RCCL merge (bitmap slices all_to_all + one all_reduce).
 
 Rank 0 prints ONE JSON line (metric, roofline, cpu_baseline).
+
+Defaults: 200 timed steps after 50 warm-up steps (1 M pairs each); the full-size cross-check against the reference's
+cell placement, the random-line probe, the host-buffer leg, the nk10 FASTQ.gz leg and the CPU baseline all run AFTER the
+timed region.  Development aids (never part of the metric): KID_BENCH_RANDOM_READS=1 (reads without a database k-mer),
+KID_BENCH_ABLATION=1 (accept builds whose counters are wrong on purpose: tools/ab_bench.py with -DKID_ABLATE_* libraries).
 """
 import argparse
 import json
