@@ -114,6 +114,9 @@ int kid_sample_begin(kid_db *db, kid_sample **out);
                                   final when the call is made and stays untouched until the batch is through (e.g. batches
                                   resident in HBM): the library may then pack a batch on a stream of its own while the batch
                                   before is still being classified, instead of strictly behind it in `stream` */
+#define KID_OPT_LONG_RECORD_KMERS 2 /* value: records of more k-mers than this (default 65536; 0 = never) are classified by
+                                      the long-record kernels -- every k-mer looked up by a lane of its own, one ordered
+                                      fold per record -- instead of by one wavefront (FASTA contigs, kmer_read_vf6.cpp:803-861) */
 int kid_sample_set_option(kid_sample *s, int option, int value);
 int kid_sample_reset(kid_sample *s);
 void kid_sample_destroy(kid_sample *s);
@@ -146,6 +149,21 @@ int kid_classify_batch_async(kid_sample *s, const uint8_t *bases, const uint64_t
 /* fixed-length whole reads laid out back to back in host memory (no offsets array to upload) */
 int kid_classify_fixed_async(kid_sample *s, const uint8_t *bases, uint32_t read_len, uint64_t n_reads,
                              uint32_t *out_final_targ, uint64_t *ticket);
+/* A block of FASTQ text, asynchronous like kid_classify_batch_async: the caller has only FOUND the lines (the part of
+ * process_fqgz, newkmer_10nx.cpp:762-816, that is inflate + splitting at '\n'); process_qual (:714-760), its
+ * "stop - start >= 30" test (:757) and process_read run on the GPU for every record.
+ *   text[text_nbytes]  the block as it came out of the file (< 4 GiB); recs[r] = byte offsets / lengths of the sequence
+ *                      line and the quality line of record r (without '\n' / '\r')
+ *   out_start/out_stop what process_qual computed; the reference hands the read to process_read iff stop - start >= k
+ *                      -- records that fail the test are counted nowhere (gcount, ucount and "reads loaded" do not see
+ *                      them) and get out_final_targ = 0
+ * A quality line shorter than its sequence (std::out_of_range in the reference, :727) is reported as KID_ERR_FORMAT
+ * by kid_sample_end / kid_sample_gcount.                                                                        */
+typedef struct kid_fastq_rec {
+    uint32_t seq_off, seq_len, qual_off, qual_len;
+} kid_fastq_rec;
+int kid_classify_fastq_async(kid_sample *s, const uint8_t *text, uint64_t text_nbytes, const kid_fastq_rec *recs,
+                             uint64_t n_reads, uint32_t *out_final_targ, int32_t *out_start, int32_t *out_stop, uint64_t *ticket);
 int kid_classify_wait(kid_sample *s, uint64_t ticket);
 /* pinned (page-locked) host memory for the buffers above, placed on the NUMA node `device` is attached to */
 int kid_host_alloc(int device, uint64_t nbytes, void **ptr);

@@ -83,6 +83,22 @@ def cli_path(name):
     return os.path.join(BIN_DIR, name)
 
 
+def build_tools(force=False, verbose=False):
+    """kid_synth_files: the synthetic workload written as the files the reference's programs read (a full-scale
+    probes10.txt.gz, FASTQ.gz pairs); plain C++ + zlib, no GPU."""
+    src = os.path.join(ROOT, "tools", "kid_synth_files.cpp")
+    out = os.path.join(BIN_DIR, "kid_synth_files")
+    if not os.path.exists(src):
+        return None
+    os.makedirs(BIN_DIR, exist_ok=True)
+    if force or _newer(out, [src, os.path.join(CSRC, "kid_common.h")]):
+        cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-Wall", "-o", out, src, "-lz", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return out
+
+
 def build_oracle(verbose=False):
     """The plain-C checker (test infrastructure) and, where the reference sources are
     present (build container only), the compiled reference under oracle/_ref."""
@@ -96,4 +112,5 @@ def build_oracle(verbose=False):
 def build_all(force=False, verbose=False):
     build_library(force=force, verbose=verbose)
     build_cli(force=force, verbose=verbose)
+    build_tools(force=force, verbose=verbose)
     build_oracle(verbose=verbose)

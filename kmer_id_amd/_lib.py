@@ -49,6 +49,8 @@ PROTOTYPES = {
     "kid_classify_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "kid_classify_batch_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, c_u64p]),
     "kid_classify_fixed_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, c_u64p]),
+    "kid_classify_fastq_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, c_u64p]),
     "kid_classify_wait": (C.c_int, [C.c_void_p, C.c_uint64]),
     "kid_host_alloc": (C.c_int, [C.c_int, C.c_uint64, c_void_pp]),
     "kid_host_free": (C.c_int, [C.c_void_p]),
@@ -84,6 +86,7 @@ PROTOTYPES = {
 }
 
 KID_OPT_INPUTS_READY = 1
+KID_OPT_LONG_RECORD_KMERS = 2
 KID_FLAG_U_IS_T = 1
 KID_FLAG_HOST_BUILD = 2
 KID_FLAG_REF_GEOMETRY = 4

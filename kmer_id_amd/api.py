@@ -190,13 +190,43 @@ class Sample:
         check(self._lib.kid_classify_batch(self._h, _ptr(bases), _ptr(offsets), _ptr(start), _ptr(stop), n, _ptr(out)))
         return out
 
+    @staticmethod
+    def _borrowed(a, dtype, name):
+        """an array the library reads / writes in place until wait(): it must already be what the C ABI expects"""
+        if a is None:
+            return None
+        if not isinstance(a, np.ndarray) or a.dtype != np.dtype(dtype) or not a.flags["C_CONTIGUOUS"]:
+            raise TypeError("%s must be a C-contiguous numpy array of %s (it is handed to the library as it is, not copied)" % (name, np.dtype(dtype)))
+        return a
+
     def classify_async(self, bases, offsets, start=None, stop=None, out=None):
         """Queue a batch held in host memory (numpy arrays or PinnedBuffer views, which the caller keeps alive and
-        untouched until wait(ticket)); -> ticket.  `out`: uint32[n] array that receives final_targ."""
+        untouched until wait(ticket)); -> ticket.  `out`: uint32[n] array that receives final_targ (or None)."""
+        bases = self._borrowed(bases, np.uint8, "bases")
+        offsets = self._borrowed(offsets, np.uint64, "offsets")
+        start = self._borrowed(start, np.int32, "start")
+        stop = self._borrowed(stop, np.int32, "stop")
+        out = self._borrowed(out, np.uint32, "out")
         n = offsets.size - 1
+        if out is not None and out.size < n:
+            raise ValueError("out holds fewer than %d entries" % n)
         t = C.c_uint64(0)
         check(self._lib.kid_classify_batch_async(self._h, _ptr(bases), _ptr(offsets), _ptr(start), _ptr(stop), n, _ptr(out), C.byref(t)))
         return t.value
+
+    def classify_fastq(self, text, recs):
+        """A block of FASTQ text with its line index (uint32[n, 4]: seq_off, seq_len, qual_off, qual_len): process_qual,
+        the >= k test and process_read on the GPU (kid_classify_fastq_async).  -> (final_targ, start, stop)"""
+        text = _as(np.frombuffer(text, np.uint8) if isinstance(text, (bytes, bytearray)) else text, np.uint8)
+        recs = _as(recs, np.uint32).reshape(-1, 4)
+        n = recs.shape[0]
+        final = np.empty(n, np.uint32)
+        start = np.empty(n, np.int32)
+        stop = np.empty(n, np.int32)
+        t = C.c_uint64(0)
+        check(self._lib.kid_classify_fastq_async(self._h, _ptr(text), text.size, _ptr(recs), n, _ptr(final), _ptr(start), _ptr(stop), C.byref(t)))
+        self.wait(t.value)
+        return final, start, stop
 
     def classify_fixed_async(self, bases_ptr, read_len, n_reads, out_ptr=0):
         """fixed-length whole reads back to back at the raw host address bases_ptr; -> ticket"""

@@ -88,12 +88,12 @@ struct kid_sample {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed; // around each classify launch, while timing is on
     uint64_t timed_batches = 0;
-    // per-batch scratch of the device pipeline (prepare -> pack -> classify), grown on demand
-    uint32_t *d_dyn = nullptr;     // chunk counters of the pair kernel's dynamic tail (KID_DYN_SHARDS x 64 bytes)
     uint32_t batch_seq = 0;
-    // Per-batch scratch of the device pipeline (pack -> prepare -> classify), grown on demand.  Three sets taken in
-    // turn, so that pack + prepare of batch b + 1 can run (on another stream) while the classify kernels of batch b
-    // still read theirs: the packed image, the descriptors and the device argument block the kernels find them in.
+    // Per-batch scratch of the device pipeline (prepare -> classify), grown on demand.  Three sets taken in turn, so
+    // that the prepare kernel of batch b + 1 can run (on another stream) while the classify kernels of batch b still
+    // read theirs: the descriptors and the device argument block the kernels find them in.  (The read text is not
+    // copied: the classify kernels read the caller's ASCII and pack in registers.  Only a batch with very long records
+    // gets a packed image, for the long-record kernels.)
     struct Scratch {
         KidReadDesc *desc = nullptr;
         uint64_t desc_cap = 0;
@@ -101,7 +101,7 @@ struct kid_sample {
         uint16_t *inval = nullptr;
         uint64_t chunks_cap = 0;
         KidRareArgs *rare = nullptr;  // device copy, written in kid_sample_begin (per batch: batch_max, desc, out_final)
-        hipEvent_t ev_prep = nullptr; // pack + prepare of the batch using the set are done
+        hipEvent_t ev_prep = nullptr; // the prepare kernel (+ pack) of the batch using the set is done
         hipEvent_t ev_used = nullptr; // ... its classify kernels are done: the set may be overwritten (recorded when a pack on another stream asks)
         hipStream_t used_stream = nullptr; // the stream those classify kernels were queued on
         bool used_recorded = false;        // ev_used was recorded right behind them
@@ -110,8 +110,14 @@ struct kid_sample {
     static const int NSET = 3;
     Scratch sets[NSET];
     uint32_t next_set = 0;
-    hipStream_t prep_stream = nullptr; // pack + prepare of the *_device entry points when the caller promised KID_OPT_INPUTS_READY
+    hipStream_t prep_stream = nullptr; // the prepare kernel of kid_classify_batch_device when the caller promised KID_OPT_INPUTS_READY
     bool inputs_ready = false;
+    int64_t long_kmers = 65536; // records of more k-mers than this take the long-record kernels (KID_OPT_LONG_RECORD_KMERS)
+    // fixed-layout batches have no descriptors and no prepare kernel: one argument block of their own, rewritten (a
+    // one-thread kernel in stream order) only when a launch differs from what the block holds
+    KidRareArgs *rare_fixed = nullptr;
+    struct { uint32_t *out_final = nullptr; uint64_t read0 = 0; uint32_t fixed_len = 0; int32_t fixed_nk = 0; bool valid = false; } fixed_held;
+    uint64_t dev_clock_batches = 0; // batches since kid_sample_kernel_time_device was last asked
     // very long records of host batches: their list and one word per k-mer position for the hits
     KidLongRec *long_recs = nullptr;
     uint64_t long_recs_cap = 0;
@@ -133,6 +139,8 @@ struct kid_sample {
         int32_t *start = nullptr, *stop = nullptr;
         uint32_t *out = nullptr;
         uint64_t reads_cap = 0;
+        KidFastqRec *recs = nullptr; // kid_classify_fastq_async: where the host found the lines of the block's records
+        uint64_t recs_cap = 0;
         hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_out = nullptr;
         std::vector<uint64_t> rel; // offsets rebased to the slot (alive until the copy has been issued AND done)
         KidLongPlan plan;          // the batch's very long records
@@ -595,7 +603,7 @@ extern "C" void kid_sample_destroy(kid_sample *s)
     if (s->long_recs) hipFree(s->long_recs);
     if (s->long_hits) hipFree(s->long_hits);
     if (s->long_tiles) hipFree(s->long_tiles);
-    if (s->d_dyn) hipFree(s->d_dyn);
+    if (s->rare_fixed) hipFree(s->rare_fixed);
     if (s->order_ev) hipEventDestroy(s->order_ev);
     hipDeviceSynchronize();
     for (kid_sample::Slot &sl : s->slots) {
@@ -604,6 +612,7 @@ extern "C" void kid_sample_destroy(kid_sample *s)
         if (sl.start) hipFree(sl.start);
         if (sl.stop) hipFree(sl.stop);
         if (sl.out) hipFree(sl.out);
+        if (sl.recs) hipFree(sl.recs);
         if (sl.ev_h2d) hipEventDestroy(sl.ev_h2d);
         if (sl.ev_done) hipEventDestroy(sl.ev_done);
         if (sl.ev_out) hipEventDestroy(sl.ev_out);
@@ -624,6 +633,11 @@ extern "C" int kid_sample_reset(kid_sample *s)
     KID_HIP(hipMemset(s->gcount, 0, nt * 8));
     KID_HIP(hipMemset(s->ucount, 0, nt * 8));
     KID_HIP(hipMemset(s->stats, 0, 256));
+    {   // device-clock stamps of a launch: [30] first workgroup start (min), [31] last end (max); see kid_classify_kernel
+        const unsigned long long never = ~0ull;
+        KID_HIP(hipMemcpy(s->stats + 30, &never, 8, hipMemcpyHostToDevice));
+    }
+    s->dev_clock_batches = 0;
     s->reads_submitted = 0;
     KID_HIP(hipMemset(s->seen, 0, s->seen_words * 4));
     KID_HIP(hipDeviceSynchronize());
@@ -654,20 +668,15 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
     KID_S_HIP(hipMalloc(&s->seen, s->seen_words * 4));
     KID_S_HIP(hipStreamCreate(&s->stream));
     {
-#ifdef KID_ENDHIST
-        const size_t dyn_bytes = KID_DYN_SHARDS * 64 + 16 * 16384; // + a record per wave (development aid)
-#else
-        const size_t dyn_bytes = KID_DYN_SHARDS * 64;
-#endif
-        KID_S_HIP(hipMalloc(&s->d_dyn, dyn_bytes));
-        KID_S_HIP(hipMemset(s->d_dyn, 0, dyn_bytes));
-        const KidRareArgs ra{s->gcount, s->stats, db->d.line_mask, 0u, s->d_dyn, 0ull, db->rows, s->seen, nullptr, nullptr};
+        const KidRareArgs ra{s->gcount, s->stats, db->d.line_mask, 0u, 0ull, 0ull, 0, 0u, db->rows, s->seen, nullptr, nullptr};
         for (kid_sample::Scratch &sc : s->sets) {
             KID_S_HIP(hipMalloc(&sc.rare, sizeof(ra)));
             KID_S_HIP(hipMemcpy(sc.rare, &ra, sizeof(ra), hipMemcpyHostToDevice));
             KID_S_HIP(hipEventCreateWithFlags(&sc.ev_prep, hipEventDisableTiming));
             KID_S_HIP(hipEventCreateWithFlags(&sc.ev_used, hipEventDisableTiming));
         }
+        KID_S_HIP(hipMalloc(&s->rare_fixed, sizeof(ra)));
+        KID_S_HIP(hipMemcpy(s->rare_fixed, &ra, sizeof(ra), hipMemcpyHostToDevice));
     }
 #undef KID_S_HIP
     rc = kid_sample_reset(s);
@@ -676,26 +685,31 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
     return KID_OK;
 }
 
-// One batch = four launches on `stream`: kid_prepare_kernel (read descriptors, range checks, longest
-// read), kid_pack_kernel (ASCII -> 2 bit + invalid mask over the whole buffer, every lane busy) and the
-// two instantiations of kid_classify_kernel (512-thread workgroups = 8 waves, persistent over the
-// reads; pair loop / general loops -- the one the batch is not for returns at once; the gcount
-// histogram lives in LDS when 4 workgroups per CU still fit).
+// One batch on `stream`: kid_prepare_kernel (read descriptors, range checks, longest read -- not for fixed-layout
+// batches, whose reads need no descriptors) and the instantiation(s) of kid_classify_kernel (512-thread workgroups =
+// 8 waves; pair loop / duo loop / general loops -- the ones the batch is not for return at once; the gcount histogram
+// lives in LDS when 4 workgroups per CU still fit).  The kernels read the caller's ASCII text directly.
 // max_kmers: the largest n_kmers of the batch when the host knows it (then only the kernel the batch is for is
 // launched), -1 when only the device does
-// prep_stream: where pack + prepare run.  The same as `stream` unless the read text is known to be ready earlier
-// than stream order says (host path: the copy stream behind the upload; device entry points under
-// KID_OPT_INPUTS_READY: an internal stream) -- then they overlap with the classify kernels of the batch before.
+// prep_stream: where the prepare kernel runs.  The same as `stream` unless the read text is known to be ready earlier
+// than stream order says (host path: the copy stream behind the upload; kid_classify_batch_device under
+// KID_OPT_INPUTS_READY: an internal stream) -- then it overlaps with the classify kernels of the batch before.
+// fastq: the batch is a block of FASTQ text with the host's line index (kid_classify_fastq_async); b.bases = the text,
+// b.start / b.stop = device arrays that RECEIVE what process_qual computes
+struct KidFastqIn {
+    const KidFastqRec *recs;
+};
 static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_nbytes, hipStream_t stream, int64_t max_kmers,
-                               hipStream_t prep_stream, const KidLongPlan *plan = nullptr)
+                               hipStream_t prep_stream, const KidLongPlan *plan = nullptr, const KidFastqIn *fastq = nullptr)
 {
     kid_db *db = s->db;
     if (b.n == 0) return KID_OK;
     if (b.n > 0x7FFFFFFFull) return kid_fail(KID_ERR_ARG, "at most 2^31-1 reads per batch");
     if (bases_nbytes >> 48) return kid_fail(KID_ERR_ARG, "a batch of 2^48 bytes or more");
-    const uint64_t nchunks = (bases_nbytes + 15) / 16;
+    const bool fixed = b.offsets == nullptr && !fastq; // fixed layout: whole reads of b.fixed_len bases back to back
+    const bool have_plan = plan && !plan->recs.empty();
     // The classify kernels of a sample's batches run one after the other (they share the sample's counters' timing
-    // stamps and chunk counters): a batch issued on another stream than the one before is made to wait for it.
+    // stamps and argument blocks): a batch issued on another stream than the one before is made to wait for it.
     if (s->has_last_stream && s->last_stream != stream) {
         if (!s->order_ev) KID_HIP(hipEventCreateWithFlags(&s->order_ev, hipEventDisableTiming));
         KID_HIP(hipEventRecord(s->order_ev, s->last_stream));
@@ -703,45 +717,55 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     }
     s->last_stream = stream;
     s->has_last_stream = true;
-    kid_sample::Scratch &sc = s->sets[s->next_set++ % kid_sample::NSET];
-    if (b.n > sc.desc_cap || nchunks > sc.chunks_cap) KID_HIP(hipDeviceSynchronize()); // (scratch in use is not freed)
-    if (b.n > sc.desc_cap) {
-        if (sc.desc) hipFree(sc.desc);
-        sc.desc = nullptr; sc.desc_cap = 0;
-        KID_HIP(hipMalloc(&sc.desc, b.n * sizeof(KidReadDesc)));
-        sc.desc_cap = b.n;
-    }
-    if (nchunks > sc.chunks_cap) {
-        if (sc.codes) hipFree(sc.codes);
-        if (sc.inval) hipFree(sc.inval);
-        sc.codes = nullptr; sc.inval = nullptr; sc.chunks_cap = 0;
-        KID_HIP(hipMalloc(&sc.codes, (nchunks + 64) * 4));
-        KID_HIP(hipMalloc(&sc.inval, (nchunks + 64) * 2));
-        sc.chunks_cap = nchunks;
-    }
-    // The batch that used this set three batches ago must be through its classify kernels before the set is overwritten.
-    // On the stream those kernels ran on that is a matter of stream order; only a different pack stream needs an event --
-    // recorded now, behind everything queued on that stream so far (an event per batch, recorded and waited for, kept the
-    // GPU idle for ~10 us of every 1.1-ms step).
-    if (sc.used && sc.used_stream != prep_stream) {
-        // (recorded behind the set's classify kernels when those ran beside a pack stream -- the host path; else now,
-        //  behind everything queued on that stream so far)
-        if (sc.used_recorded || hipEventRecord(sc.ev_used, sc.used_stream) == hipSuccess) KID_HIP(hipStreamWaitEvent(prep_stream, sc.ev_used, 0));
-        else { // (a caller's stream that is gone by now: everything queued on it has run or the device is in error)
-            (void)hipGetLastError();
-            KID_HIP(hipDeviceSynchronize());
+    kid_sample::Scratch *scp = nullptr;
+    KidRareArgs *rare = s->rare_fixed;
+    if (!fixed) {
+        kid_sample::Scratch &sc = s->sets[s->next_set++ % kid_sample::NSET];
+        scp = &sc;
+        rare = sc.rare;
+        const uint64_t nchunks = have_plan ? (bases_nbytes + 15) / 16 : 0;
+        if (b.n > sc.desc_cap || nchunks > sc.chunks_cap) KID_HIP(hipDeviceSynchronize()); // (scratch in use is not freed)
+        if (b.n > sc.desc_cap) {
+            if (sc.desc) hipFree(sc.desc);
+            sc.desc = nullptr; sc.desc_cap = 0;
+            KID_HIP(hipMalloc(&sc.desc, b.n * sizeof(KidReadDesc)));
+            sc.desc_cap = b.n;
         }
-    }
-    const bool fuse_rebase = prep_stream == stream;
-    if (nchunks)
-        hipLaunchKernelGGL(kid_pack_kernel, dim3(kid_grid_for(nchunks, 256, db->num_cu * 16)), dim3(256), 0, prep_stream, b.bases,
-                           nchunks, db->d.u_is_t, sc.codes, sc.inval);
-    hipLaunchKernelGGL(kid_prepare_kernel, dim3(kid_grid_for(b.n, 256, db->num_cu * 8)), dim3(256), 0, prep_stream, b, db->info.k,
-                       sc.desc, s->stats, sc.rare, ++s->batch_seq, nchunks ? sc.inval : nullptr, plan ? plan->cut : 0u,
-                       fuse_rebase ? 1 : 0);
-    if (prep_stream != stream) {
-        KID_HIP(hipEventRecord(sc.ev_prep, prep_stream));
-        KID_HIP(hipStreamWaitEvent(stream, sc.ev_prep, 0));
+        if (nchunks > sc.chunks_cap) { // the packed image the long-record kernels index by position
+            if (sc.codes) hipFree(sc.codes);
+            if (sc.inval) hipFree(sc.inval);
+            sc.codes = nullptr; sc.inval = nullptr; sc.chunks_cap = 0;
+            KID_HIP(hipMalloc(&sc.codes, (nchunks + 64) * 4));
+            KID_HIP(hipMalloc(&sc.inval, (nchunks + 64) * 2));
+            sc.chunks_cap = nchunks;
+        }
+        // The batch that used this set three batches ago must be through its classify kernels before the set is overwritten.
+        // On the stream those kernels ran on that is a matter of stream order; only a different prepare stream needs an
+        // event -- recorded behind the set's classify kernels when those ran beside a prepare stream (the host path), else
+        // now, behind everything queued on that stream so far (an event per batch, recorded and waited for, kept the GPU idle
+        // for ~10 us of every step).
+        if (sc.used && sc.used_stream != prep_stream) {
+            if (sc.used_recorded || hipEventRecord(sc.ev_used, sc.used_stream) == hipSuccess) KID_HIP(hipStreamWaitEvent(prep_stream, sc.ev_used, 0));
+            else { // (a caller's stream that is gone by now: everything queued on it has run or the device is in error)
+                (void)hipGetLastError();
+                KID_HIP(hipDeviceSynchronize());
+            }
+        }
+        const bool fuse_rebase = prep_stream == stream;
+        if (nchunks)
+            hipLaunchKernelGGL(kid_pack_kernel, dim3(kid_grid_for(nchunks, 256, db->num_cu * 16)), dim3(256), 0, prep_stream, b.bases,
+                               nchunks, db->d.u_is_t, sc.codes, sc.inval);
+        if (fastq)
+            hipLaunchKernelGGL(kid_prepare_fastq_kernel, dim3(kid_grid_for(b.n, 256, db->num_cu * 8)), dim3(256), 0, prep_stream, b.bases,
+                               fastq->recs, b.n, db->info.k, sc.desc, const_cast<int32_t *>(b.start), const_cast<int32_t *>(b.stop),
+                               b.out_final, s->stats, s->gcount, sc.rare, ++s->batch_seq, fuse_rebase ? 1 : 0);
+        else
+            hipLaunchKernelGGL(kid_prepare_kernel, dim3(kid_grid_for(b.n, 256, db->num_cu * 8)), dim3(256), 0, prep_stream, b, db->info.k,
+                               sc.desc, s->stats, sc.rare, ++s->batch_seq, have_plan ? plan->cut : 0u, fuse_rebase ? 1 : 0);
+        if (prep_stream != stream) {
+            KID_HIP(hipEventRecord(sc.ev_prep, prep_stream));
+            KID_HIP(hipStreamWaitEvent(stream, sc.ev_prep, 0));
+        }
     }
     const int block = 512, wpb = block / 64;
     const uint32_t ntar = (uint32_t)db->info.ntar;
@@ -752,9 +776,8 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     // Workgroups per CU in the grid.  Four are resident; the SIMDs serve their oldest waves first, so equal shares
     // finish far apart (45 % .. 100 % of a launch) and a grid of exactly the resident workgroups ends at a falling
     // occupancy.  With 16 per CU the dispatcher hands a new workgroup to a CU whenever one is through: 0.97 instead of
-    // 1.02 ms per 2 M reads (profiles/r02/ab_grid_mult.txt).  KID_GRID_MULT overrides (experiments).
-    static const int grid_mult = getenv("KID_GRID_MULT") ? atoi(getenv("KID_GRID_MULT")) : 16;
-    const int grid = kid_grid_for(b.n, wpb, db->num_cu * (grid_mult > 0 ? grid_mult : 16));
+    // 1.02 ms per 2 M reads (profiles/r02/ab_grid_mult.txt).
+    const int grid = kid_grid_for(b.n, wpb, db->num_cu * 16);
     const uint32_t hist_words32 = (ntar + 3u) & ~3u, hist_words16 = ((ntar + 1u) / 2u + 3u) & ~3u;
     const uint32_t hist_words = ml ? hist_words16 : hist_words32;
     const uint32_t wave_words = ml ? KID_GEN_ML_LDS_WORDS : KID_WAVE_LDS_WORDS;
@@ -762,15 +785,16 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     const bool hist_pair = (hist_words16 + wpb * KID_PAIR_LDS_WORDS) * 4u + 32u <= 40u * 1024u;
     uint64_t span = b.n;
     if (ml && (hist || hist_pair)) {
-        // reads per launch: < 65536 per workgroup -- and with the pair kernel's tapered shares (KID_TAPER) the workgroups
-        // dispatched first take up to 1.5 x the average (+ rounding to whole units per wave)
-        const uint64_t per_wg = KID_TAPER ? (uint64_t)(65535u - 2u * (uint32_t)wpb - 64u * (uint32_t)wpb) * (KID_TAPER + 1u) / (2u * KID_TAPER) : 65535u - 2u * (uint32_t)wpb;
+        // reads per launch: < 65536 per workgroup -- and with the tapered shares (KID_TAPER) the workgroups dispatched
+        // first take up to 1.7 x the average (+ rounding to whole units per wave)
+        const uint64_t per_wg = (uint64_t)(65535u - 2u * (uint32_t)wpb - 64u * (uint32_t)wpb) * (KID_TAPER + 1u) / (2u * KID_TAPER);
         // (the bound assumes the two halves of the grid are equal: an odd grid -- only ever a small one -- gets half of it)
-        const uint64_t cap = (uint64_t)grid * ((KID_TAPER && (grid & 1)) ? per_wg / 2 : per_wg);
+        const uint64_t cap = (uint64_t)grid * ((grid & 1) ? per_wg / 2 : per_wg);
         if (span > cap) span = cap;
     }
     KidSampleDev sd{s->gcount, s->seen, s->stats};
     const bool rows = db->rows != nullptr;
+    const int32_t fixed_nk = fixed ? (int32_t)(max_kmers > 0 ? max_kmers : 0) : 0;
     KidEvent ev0, ev1;
     if (s->timing) {
         KID_HIP(ev0.create());
@@ -779,31 +803,38 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     }
     for (uint64_t r0 = 0; r0 < b.n; r0 += span) {
     const uint64_t cnt = b.n - r0 < span ? b.n - r0 : span;
-    KidPacked pk{sc.codes, sc.inval, sc.desc + r0, b.out_final ? b.out_final + r0 : nullptr, cnt};
-    // the kernels find this launch's descriptors and result array in the set's device argument block; the first launch
-    // of a batch also banks / arms the device-clock stamps (here, in classify-stream order: prepare may run early)
-    if (r0 != 0 || !fuse_rebase) // (the first launch of a batch prepared on this stream: done by kid_prepare_kernel)
-        hipLaunchKernelGGL(kid_rebase_kernel, dim3(1), dim3(64), 0, stream, sc.rare, pk.desc, pk.out_final, s->stats, r0 == 0 ? 1 : 0);
+    KidInput pk{b.bases, fixed ? nullptr : scp->desc + r0, b.out_final ? b.out_final + r0 : nullptr, cnt};
+    // the kernels find this launch's descriptors (or the fixed layout) and result array in the device argument block
+    if (fixed) {
+        auto &h = s->fixed_held;
+        if (!h.valid || h.out_final != pk.out_final || h.read0 != r0 || h.fixed_len != b.fixed_len || h.fixed_nk != fixed_nk) {
+            hipLaunchKernelGGL(kid_rebase_kernel, dim3(1), dim3(64), 0, stream, rare, (const KidReadDesc *)nullptr, pk.out_final,
+                               (unsigned long long)r0, b.fixed_len, fixed_nk, (1ull << 32) | (unsigned long long)fixed_nk);
+            h.valid = true; h.out_final = pk.out_final; h.read0 = r0; h.fixed_len = b.fixed_len; h.fixed_nk = fixed_nk;
+        }
+    } else if (r0 != 0 || prep_stream != stream) { // (the first launch of a batch prepared on this stream: done by kid_prepare_kernel)
+        hipLaunchKernelGGL(kid_rebase_kernel, dim3(1), dim3(64), 0, stream, rare, pk.desc, pk.out_final, 0ull, 0u, 0, 0ull);
+    }
 #define KID_LAUNCH1(R, H, M, KF, PK)                                                                                            \
     hipLaunchKernelGGL((kid_classify_kernel<2, R, H, M, KF, PK>), dim3(grid), dim3(block),                                     \
                        (((H) ? ((PK) ? hist_words16 : hist_words) : 0u) +                                                       \
                         (size_t)wpb * ((PK) ? KID_PAIR_LDS_WORDS : wave_words)) * 4 + 32, stream,                              \
-                       db->d, pk, sd, (H) ? ((PK) ? hist_words16 : hist_words) : 0u, pk.desc, sc.rare)
+                       db->d, pk, sd, (H) ? ((PK) ? hist_words16 : hist_words) : 0u, pk.desc, rare)
 #define KID_LAUNCH(R, H, M)                                                                                                    \
     do {                                                                                                                       \
         if (db->info.k == 30) KID_LAUNCH1(R, H, M, 30, 0);                                                                     \
         else KID_LAUNCH1(R, H, M, 0, 0);                                                                                       \
     } while (0)
-    // the minimizer-localised table has two kernels per batch (see kid_classify_kernel): pair loop, general loops
+    // the minimizer-localised table has three kernels (see kid_classify_kernel): pair loop, duo loop, general loops
 #define KID_LAUNCH_PK(R, H, MODE)                                                                                              \
     do {                                                                                                                       \
         if (db->info.k == 30) KID_LAUNCH1(R, H, true, 30, MODE);                                                               \
         else KID_LAUNCH1(R, H, true, 0, MODE);                                                                                 \
     } while (0)
     // kernel 1: pairs of single-group reads (<= 128 k-mers); kernel 2: the two groups of a read (<= 256); kernel 0: the rest
-    const bool want_pair = ml && KID_PAIRS && (max_kmers < 0 || max_kmers <= 2 * 64);
-    const bool want_duo = ml && KID_PAIRS && (max_kmers < 0 || (max_kmers > 2 * 64 && max_kmers <= 4 * 64));
-    const bool want_general = !(ml && KID_PAIRS) || max_kmers < 0 || max_kmers > 4 * 64;
+    const bool want_pair = ml && (max_kmers < 0 || max_kmers <= 2 * 64);
+    const bool want_duo = ml && (max_kmers < 0 || (max_kmers > 2 * 64 && max_kmers <= 4 * 64));
+    const bool want_general = !ml || max_kmers < 0 || max_kmers > 4 * 64;
     if (want_pair) {
         if (rows && hist_pair) KID_LAUNCH_PK(true, true, 1);
         else if (rows) KID_LAUNCH_PK(true, false, 1);
@@ -829,7 +860,8 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
 #undef KID_LAUNCH1
 #undef KID_LAUNCH
     }
-    if (plan && !plan->recs.empty()) {
+    if (have_plan) {
+        kid_sample::Scratch &sc = *scp; // (long records only come with offsets: never a fixed-layout batch)
         // the very long records: every k-mer looked up by a lane of its own, then one workgroup per record folds its hits
         const uint64_t nrec = plan->recs.size();
         if (nrec > s->long_recs_cap || plan->total_kmers > s->long_hits_cap || plan->n_tiles > s->long_tiles_cap) KID_HIP(hipDeviceSynchronize());
@@ -866,13 +898,16 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
         s->timed.emplace_back(ev0.release(), ev1.release());
         s->timed_batches++;
     }
-    // pack and prepare on a stream of their own (the host path: they run beside the classify kernels of the batch before):
-    // the pack that overwrites this set three batches on waits for exactly these kernels, not for whatever the classify
-    // stream holds by then (148 instead of 153 M pairs/s from host buffers, profiles/r02/ab_lazy_event.txt)
-    sc.used_recorded = prep_stream != stream;
-    if (sc.used_recorded) KID_HIP(hipEventRecord(sc.ev_used, stream));
-    sc.used_stream = stream;
-    sc.used = true;
+    s->dev_clock_batches++;
+    if (scp) {
+        // prepare on a stream of its own (the host path: it runs beside the classify kernels of the batch before): the
+        // prepare that overwrites this set three batches on waits for exactly these kernels, not for whatever the classify
+        // stream holds by then (profiles/r02/ab_lazy_event.txt)
+        scp->used_recorded = prep_stream != stream;
+        if (scp->used_recorded) KID_HIP(hipEventRecord(scp->ev_used, stream));
+        scp->used_stream = stream;
+        scp->used = true;
+    }
     KID_HIP(hipGetLastError());
     s->reads_submitted += b.n;
     return KID_OK;
@@ -883,6 +918,10 @@ extern "C" int kid_sample_set_option(kid_sample *s, int option, int value)
     if (!s) return kid_fail(KID_ERR_ARG, "null sample");
     switch (option) {
     case KID_OPT_INPUTS_READY: s->inputs_ready = value != 0; return KID_OK;
+    case KID_OPT_LONG_RECORD_KMERS:
+        if (value < 0) return kid_fail(KID_ERR_ARG, "KID_OPT_LONG_RECORD_KMERS: negative threshold");
+        s->long_kmers = value;
+        return KID_OK;
     default: return kid_fail(KID_ERR_ARG, "unknown option %d", option);
     }
 }
@@ -933,13 +972,12 @@ extern "C" int kid_sample_kernel_time_device(kid_sample *s, double *total_ms, ui
     KID_HIP(hipDeviceSynchronize());
     unsigned long long st[32];
     KID_HIP(hipMemcpy(st, s->stats, sizeof(st), hipMemcpyDeviceToHost));
-    unsigned long long ticks = st[6], n = st[7];
-    if (st[31] > st[30]) { ticks += st[31] - st[30]; n++; } // the batch after which no other was prepared
-    const unsigned long long zero4[2] = {0, 0};
-    KID_HIP(hipMemcpy(s->stats + 6, zero4, 16, hipMemcpyHostToDevice));
-    KID_HIP(hipMemcpy(s->stats + 30, zero4, 16, hipMemcpyHostToDevice));
+    const unsigned long long ticks = st[6]; // banked by the last workgroup of every launch ([7]: launches)
+    const unsigned long long zero2[2] = {0, 0};
+    KID_HIP(hipMemcpy(s->stats + 6, zero2, 16, hipMemcpyHostToDevice));
     *total_ms = (double)ticks / 1e5; // s_memrealtime: 100 MHz
-    *launches = n;
+    *launches = s->dev_clock_batches; // batches, like kid_sample_kernel_time (a large batch is several launches)
+    s->dev_clock_batches = 0;
     return KID_OK;
 }
 
@@ -1033,12 +1071,12 @@ static int kid_slot_acquire(kid_sample *s, uint64_t n_reads, uint64_t nbytes, bo
 static int kid_slot_submit(kid_sample *s, kid_sample::Slot &sl, const KidBatch &b, uint64_t nbytes, int64_t max_kmers,
                            uint32_t *out_final_targ, uint64_t *ticket)
 {
-    // pack + prepare follow the upload on the copy stream (beside the classify kernels of the batch before); the
-    // classify kernels wait for them on the sample's stream
+    // the prepare kernel follows the upload on the copy stream (beside the classify kernels of the batch before); the
+    // classify kernels wait for it on the sample's stream
     KID_HIP(hipEventRecord(sl.ev_h2d, s->copy_stream));
-    static const bool dbg_no_kernels = getenv("KID_DEBUG_NO_KERNELS") != nullptr; // timing experiments only
-    int rc = dbg_no_kernels ? KID_OK : kid_launch_classify(s, b, nbytes, s->stream, max_kmers, s->copy_stream,
-                                                           sl.plan.recs.empty() ? nullptr : &sl.plan);
+    // (a fixed-layout batch has no prepare kernel on the copy stream for the classify kernels to wait for: they wait for the upload itself)
+    if (!b.offsets) KID_HIP(hipStreamWaitEvent(s->stream, sl.ev_h2d, 0));
+    int rc = kid_launch_classify(s, b, nbytes, s->stream, max_kmers, s->copy_stream, sl.plan.recs.empty() ? nullptr : &sl.plan);
     if (rc != KID_OK) return rc;
     KID_HIP(hipEventRecord(sl.ev_done, s->stream));
     if (out_final_targ) {
@@ -1065,7 +1103,7 @@ extern "C" int kid_classify_batch_async(kid_sample *s, const uint8_t *bases, con
     // A record of more than `long_cut` k-mers is a long record (a FASTA contig, kmer_read_vf6.cpp:803-861): the classify
     // kernels would give it to one wave.  If the batch holds few of them they go through the long-record kernels
     // instead; if it holds many, the waves have enough of them to keep the chip busy as it is.
-    static const int64_t long_cut = getenv("KID_LONG_KMERS") ? atoll(getenv("KID_LONG_KMERS")) : 65536;
+    const int64_t long_cut = s->long_kmers;
     static const size_t long_max = 1024;
     int64_t max_kmers = 0, max_short = 0;
     std::vector<KidLongRec> longs;
@@ -1160,6 +1198,61 @@ extern "C" int kid_classify_fixed_async(kid_sample *s, const uint8_t *bases, uin
     b.fixed_len = read_len;
     const int64_t nk = (int64_t)read_len - s->db->info.k + 1;
     return kid_slot_submit(s, sl, b, nbytes, nk > 0 ? nk : 0, out_final_targ, ticket);
+}
+
+// A block of FASTQ text whose lines the caller has found: quality trimming (process_qual), the ">= k" test and
+// process_read all happen on the GPU; the host's share of process_fqgz (newkmer_10nx.cpp:762-816) is inflate + memchr.
+extern "C" int kid_classify_fastq_async(kid_sample *s, const uint8_t *text, uint64_t text_nbytes, const kid_fastq_rec *recs,
+                                        uint64_t n_reads, uint32_t *out_final_targ, int32_t *out_start, int32_t *out_stop,
+                                        uint64_t *ticket)
+{
+    static_assert(sizeof(kid_fastq_rec) == sizeof(KidFastqRec), "kid_fastq_rec is the device record");
+    if (!s) return kid_fail(KID_ERR_ARG, "null sample");
+    if (ticket) *ticket = 0;
+    if (n_reads == 0) return KID_OK;
+    if (!text || !recs || !out_start || !out_stop) return kid_fail(KID_ERR_ARG, "null argument");
+    if (text_nbytes >= 0xFFFFFFFFull) return kid_fail(KID_ERR_ARG, "a FASTQ block of 4 GiB or more");
+    for (uint64_t r = 0; r < n_reads; r++)
+        if ((uint64_t)recs[r].seq_off + recs[r].seq_len > text_nbytes || (uint64_t)recs[r].qual_off + recs[r].qual_len > text_nbytes)
+            return kid_fail(KID_ERR_ARG, "record %llu lies outside the text block", (unsigned long long)r);
+    int rc = kid_use_device(s->db->device);
+    if (rc != KID_OK) return rc;
+    kid_sample::Slot *slp = nullptr;
+    rc = kid_slot_acquire(s, n_reads, text_nbytes, true, true, &slp);
+    if (rc != KID_OK) return rc;
+    kid_sample::Slot &sl = *slp;
+    if (n_reads > sl.recs_cap) {
+        if (sl.recs) KID_HIP(hipFree(sl.recs));
+        sl.recs = nullptr; sl.recs_cap = 0;
+        const uint64_t cap = n_reads + n_reads / 8;
+        KID_HIP(hipMalloc(&sl.recs, cap * sizeof(KidFastqRec)));
+        sl.recs_cap = cap;
+    }
+    hipStream_t cs = s->copy_stream;
+    const uint64_t need = ((text_nbytes + 15) & ~15ull) + 32;
+    KID_HIP(hipMemsetAsync(sl.bases + (text_nbytes & ~15ull), 0, need - (text_nbytes & ~15ull), cs));
+    KID_HIP(hipMemcpyAsync(sl.bases, text, text_nbytes, hipMemcpyHostToDevice, cs));
+    KID_HIP(hipMemcpyAsync(sl.recs, recs, n_reads * sizeof(KidFastqRec), hipMemcpyHostToDevice, cs));
+    KidBatch b{};
+    b.bases = sl.bases;
+    b.start = sl.start; // (outputs of the prepare kernel here)
+    b.stop = sl.stop;
+    b.out_final = sl.out;
+    b.n = n_reads;
+    KidFastqIn fq{sl.recs};
+    KID_HIP(hipEventRecord(sl.ev_h2d, s->copy_stream));
+    rc = kid_launch_classify(s, b, text_nbytes, s->stream, -1, s->copy_stream, nullptr, &fq);
+    if (rc != KID_OK) return rc;
+    KID_HIP(hipEventRecord(sl.ev_done, s->stream));
+    KID_HIP(hipStreamWaitEvent(s->out_stream, sl.ev_done, 0));
+    if (out_final_targ) KID_HIP(hipMemcpyAsync(out_final_targ, sl.out, n_reads * 4, hipMemcpyDeviceToHost, s->out_stream));
+    KID_HIP(hipMemcpyAsync(out_start, sl.start, n_reads * 4, hipMemcpyDeviceToHost, s->out_stream));
+    KID_HIP(hipMemcpyAsync(out_stop, sl.stop, n_reads * 4, hipMemcpyDeviceToHost, s->out_stream));
+    KID_HIP(hipEventRecord(sl.ev_out, s->out_stream));
+    sl.busy = true;
+    sl.ticket = s->next_ticket++;
+    if (ticket) *ticket = sl.ticket;
+    return KID_OK;
 }
 
 extern "C" int kid_classify_wait(kid_sample *s, uint64_t ticket)
@@ -1287,10 +1380,12 @@ extern "C" int kid_trim_batch(kid_db *db, const uint8_t *quals, const uint64_t *
 // ---------------------------------------------------------------- results
 static int kid_check_errors(kid_sample *s)
 {
-    unsigned long long st[8];
-    KID_HIP(hipMemcpy(st, s->stats, 64, hipMemcpyDeviceToHost));
+    unsigned long long st[9];
+    KID_HIP(hipMemcpy(st, s->stats, sizeof(st), hipMemcpyDeviceToHost));
     if (st[4] != 0)
         return kid_fail(KID_ERR_ARG, "%llu reads had [start,stop] outside the read (string::at would throw)", st[4]);
+    if (st[8] != 0)
+        return kid_fail(KID_ERR_FORMAT, "%llu FASTQ records have a quality line shorter than the sequence (qual.at() throws in the reference)", st[8]);
     // every read handed over was classified by exactly one of the kernels (they pick themselves by the batch's
     // longest read: a disagreement with the host's choice would show here, not as silently missing reads)
     if (st[0] != s->reads_submitted)
@@ -1393,28 +1488,6 @@ extern "C" int kid_sample_stats(kid_sample *s, uint64_t out[4])
     unsigned long long st[8];
     KID_HIP(hipMemcpy(st, s->stats, 64, hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; i++) out[i] = st[i];
-    return KID_OK;
-}
-
-// development aid (not in the public header): the per-phase cycle sums a -DKID_PROFILE build collects
-extern "C" int kid_sample_debug_counters(kid_sample *s, uint64_t out[24])
-{
-    if (!s || !out) return kid_fail(KID_ERR_ARG, "null argument");
-    int rc = kid_use_device(s->db->device);
-    if (rc != KID_OK) return rc;
-    KID_HIP(hipDeviceSynchronize());
-    KID_HIP(hipMemcpy(out, s->stats + 8, 24 * 8, hipMemcpyDeviceToHost));
-    return KID_OK;
-}
-
-// development aid (KID_ENDHIST builds): the per-wave records of the last launch
-extern "C" int kid_sample_debug_wave_records(kid_sample *s, uint32_t *out, uint64_t n_waves)
-{
-    if (!s || !out) return kid_fail(KID_ERR_ARG, "null argument");
-    int rc = kid_use_device(s->db->device);
-    if (rc != KID_OK) return rc;
-    KID_HIP(hipDeviceSynchronize());
-    KID_HIP(hipMemcpy(out, s->d_dyn + KID_DYN_SHARDS * 16, n_waves * 16, hipMemcpyDeviceToHost));
     return KID_OK;
 }
 

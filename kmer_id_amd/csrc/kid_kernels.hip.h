@@ -4,6 +4,7 @@
 // table in HBM; there is no MFMA-shaped computation on this path.
 //
 // Data layout in HBM
+//   bases   the caller's ASCII read text; the classify kernels read it as it is and pack in registers
 //   table   uint4[2^log2_slots]   {key lo, key hi, target (0 = empty), insertion ordinal+1}
 //                                 one 16-byte cell = one global_load_dwordx4 per probe
 //   rows    uint4[ntar]           8 x u16 per taxonomy node: e0 = depth, e[d] = ancestor of
@@ -15,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "kid_common.h"
 
 #define KID_WAVE 64
@@ -26,77 +28,20 @@
 #define KID_CQ_CAP 192   // a read appends at most 128 entries to fewer than KID_CQ_FLUSH queued ones
 #define KID_CQ_FLUSH 64
 #define KID_PAIR_LDS_WORDS (4 + 3 * KID_CQ_CAP + KID_CQ_CAP / 4 + 64 + 128) // ... + the batch read numbers of 128 result slots
-#ifndef KID_WORDS_MASKED
-#define KID_WORDS_MASKED 1 // pair kernels: the packed words of a read are requested by the lanes that hold words of it only
-#endif
-#ifndef KID_ROW_WORDS
-#define KID_ROW_WORDS 0 // pair kernel, 1: packed words by DPP row broadcasts instead of ds_bpermute (needs KID_WORDS_MASKED).
-                        // Bit-exact and 16 LDS instructions per pair fewer, but not faster (profiles/r02/ab_row_words.txt): kept as a switch
-#endif
-#ifndef KID_BLOCK_CYCLIC
-#define KID_BLOCK_CYCLIC 1 // pair kernel: a wave's reads are whole blocks of 64 consecutive reads (0: read i of wave w = w + i x waves)
-#endif
-#ifndef KID_SEEN_POLICY
-#define KID_SEEN_POLICY "" // cache-policy bits of the seen-bitmap atomics (" sc1", " sc0 sc1", " nt": experiments)
-#endif
-#ifndef KID_SEEN_COMBINE
-#define KID_SEEN_COMBINE 1 // resolver: hits of a pass that fall into the same word of the seen bitmap share one atomic
-#endif
-#ifndef KID_TAPER
-#define KID_TAPER 6u // pair kernel: the workgroups dispatched first take this many times the reads of those dispatched last (0: equal shares)
-#endif
-#ifndef KID_SKEW
-#define KID_SKEW 0 // pair loop, 1: the second read's header test is taken in the next trip (see the loop); 0: straight order.
-                   // Bit-exact, no faster (profiles/r02/ab_skew.txt: the loop is not bound by the wait for those headers)
-#endif
-#ifndef KID_DYNAMIC
-// 1: the waves of the pair kernel draw their reads in small blocks from counters instead of owning a fixed share.
-// Measured (profiles/r02/dynamic_blocks.txt): the SIMDs serve their oldest waves first, so with fixed shares the waves of
-// a 2 M-read launch finish anywhere between 45 % and 100 % of the launch -- but handing the work out dynamically did
-// not shorten the launch: the starved (young) waves hold their last blocks for hundreds of microseconds, and every
-// block switch costs a drain.  Off by default; the code stays for the next attempt.
-#define KID_DYNAMIC 0
-#endif
-#ifndef KID_EARLY_CAND
-// 1: a lookup whose header shows a fingerprint match fetches its candidate cell on the spot -- the cell sits in the
+#define KID_TAPER 6u // the workgroups dispatched first take this many times the reads of those dispatched last
+                     // (profiles/r02/ab_taper.txt: a launch ends when the slowest of its last workgroups does)
+// A lookup whose header shows a fingerprint match fetches its candidate cell on the spot -- the cell sits in the
 // 128-byte line the header has just brought in -- and the queue carries {target, entry ordinal} of verified hits; the
 // resolver then needs neither the header nor the cell again (by then the line is long gone from every cache: one HBM
 // line and two dependent round trips per hit saved).  Lookups that cannot be settled by their first candidate (a
-// fingerprint false positive, a full line) are queued the old way.
-#define KID_EARLY_CAND 1
-#endif
-#ifndef KID_EARLY_MAX
-#define KID_EARLY_MAX 4u // ... for tiles with at most this many flagged lookups
-#endif
-#ifndef KID_EARLY_QN
-#define KID_EARLY_QN 32u // ... while fewer than this many lookups are queued
-#endif
-#define KID_DYN_SHARDS 16u // counters the chunks are drawn from (one word takes ~90 fetches per microsecond)
-#ifndef KID_DYN_CHUNK
-#define KID_DYN_CHUNK 16u  // most reads a wave draws at a time (even)
-#endif
-#ifndef KID_DYN_MAXLEFT
-#define KID_DYN_MAXLEFT 96u // at most this many reads per wave are left to the pool
-#endif
+// fingerprint false positive, a full line) are queued with their key.  Only while hits are sparse:
+#define KID_EARLY_MAX 4u // ... tiles with at most this many flagged lookups
+#define KID_EARLY_QN 32u // ... while fewer than this many lookups are queued (profiles/r02/clumped_ec.txt)
 #define KID_GEN_ML_LDS_WORDS (104 + 3 * KID_CQ_CAP + KID_CQ_CAP / 4 + 64) // general loops on the minimizer-localised table: strip, counters, queue, results
-#if defined(KID_ABLATE) && KID_ABLATE >= 2
-#define KID_ABLATE_NOMIN 1
-#else
-#define KID_ABLATE_NOMIN 0
-#endif
-#ifndef KID_PAIRS
-#define KID_PAIRS 1 // the hand-pipelined pair loop for batches of single-group reads
-#endif
-#ifndef KID_CLASSIFY_OCC
 #define KID_CLASSIFY_OCC 8 // waves per SIMD the register allocator must leave room for
-#endif
-#ifdef KID_CLASSIFY_VGPR // experiment: a VGPR cap of its own (with KID_CLASSIFY_OCC = 7: 96 SGPRs, but still 64 VGPRs)
-#define KID_CLASSIFY_ATTR __attribute__((amdgpu_num_vgpr(KID_CLASSIFY_VGPR)))
-#else
-#define KID_CLASSIFY_ATTR
-#endif
 
 typedef uint32_t kid_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t kid_u2 __attribute__((ext_vector_type(2)));
 
 // One table cell.  Reference placement: non-temporal -- a probe touches a random 16 bytes of a 16 GiB
 // table once, so the line is not worth keeping in L2 / Infinity Cache (tools/gather_policy.hip: 49 ->
@@ -114,11 +59,7 @@ __device__ __forceinline__ void kid_store_u32_nowait(uint32_t *p, uint32_t v)
 }
 __device__ __forceinline__ void kid_atomic_or_nowait(uint32_t *p, uint32_t v)
 {
-#ifdef KID_ABLATE_SEEN_STORE // timing experiment only (wrong ucount): a plain byte store where the atomic is
-    asm volatile("global_store_byte %0, %1, off" : : "v"(p), "v"(v) : "memory");
-#else
-    asm volatile("global_atomic_or %0, %1, off" KID_SEEN_POLICY : : "v"(p), "v"(v) : "memory");
-#endif
+    asm volatile("global_atomic_or %0, %1, off" : : "v"(p), "v"(v) : "memory");
 }
 
 __device__ __forceinline__ uint4 kid_load_cell(const uint4 *table, uint32_t idx) { return table[idx]; }
@@ -162,18 +103,23 @@ struct KidReadDesc {
     uint32_t pad;
 };
 
-struct KidPacked { // what the classify kernel reads
-    const uint32_t *codes;  // one word per 16 bases of the whole batch buffer, first base in the top bits
-    const uint16_t *inval;  // one bit per base: not ACGTacgt (Uu)
-    const KidReadDesc *desc;
-    uint32_t *out_final;    // nullable
-    uint64_t n;
+// What a launch of the classify kernels reads: the ASCII read text as the caller handed it over -- the kernels turn it
+// into 2-bit codes in registers (kid_pack4 / kid_pack16), there is no packed image of the batch in memory -- and the
+// reads' descriptors.  Fixed layout (kid_classify_fixed_*): no descriptors either, read r of the launch is
+// bases[(read0 + r) * fixed_len ...) with fixed_nk k-mers (KidRareArgs).
+struct KidInput {
+    const uint8_t *bases;    // 16-byte aligned; readable up to 16 bytes past the last read
+    const KidReadDesc *desc; // of this launch's reads; null: fixed layout
+    uint32_t *out_final;     // of this launch's reads; nullable
+    uint64_t n;              // reads of this launch
 };
 
 struct KidSampleDev {
     unsigned long long *gcount;
     uint32_t *seen;
-    unsigned long long *stats; // [0] reads [1] lookups [2] probes [3] hits [4] argument errors
+    unsigned long long *stats; // [0] reads [1] lookups [2] probes [3] hits [4] argument errors [5] FASTQ records dropped by process_qual
+                               // [6] device-clock ticks [7] launches banked [8] quality lines shorter than their sequence
+                               // [29] workgroups through [30] first start [31] last end of the running launch
 };
 
 // What only rare paths of the classify kernel need (hit cells, the flush at the end): kept in device
@@ -182,15 +128,17 @@ struct KidRareArgs {
     unsigned long long *gcount;
     unsigned long long *stats;
     uint32_t line_mask;
-    uint32_t pad;
-    uint32_t *dyn; // KID_DYN_SHARDS chunk counters, 64 bytes apart; zeroed for every launch
+    uint32_t fixed_len;           // fixed layout: bases per read (0: the launch has descriptors)
     unsigned long long batch_max; // (batch sequence number << 32) | largest n_kmers of the batch: kid_prepare_kernel
+    unsigned long long read0;     // fixed layout: number of the launch's first read within the batch text
+    int32_t fixed_nk;             // fixed layout: k-mers per read
+    uint32_t pad;
     // what the resolver / the 64-read flush of the pair kernels need (rare paths by now, bulk work: a scalar
     // load there is cheaper than four scalar registers held across the hot loop)
     const uint4 *rows;
     uint32_t *seen;
-    uint32_t *out_final;   // of the current batch: written by kid_prepare_kernel
-    const void *desc;      // of the current batch (KidReadDesc *)
+    uint32_t *out_final;   // of the current launch: written by kid_prepare_kernel / kid_rebase_kernel
+    const void *desc;      // of the current launch (KidReadDesc *; null: fixed layout)
 };
 
 // ------------------------------------------------------------------ hash lookup
@@ -211,9 +159,6 @@ __device__ __forceinline__ uint32_t kid_hdr_cand(const uint4 &h, uint32_t fp)
 __device__ __forceinline__ bool kid_hdr_any(const uint4 &h, uint32_t fp)
 {
     const uint16_t f = (uint16_t)fp;
-#ifdef KID_ABLATE_HDR1 // timing experiment only (misses six of seven entries): is the loop sensitive to its VALU instruction count?
-    return (uint16_t)h.x == f;
-#endif
     return ((uint16_t)h.x == f) | ((uint16_t)(h.x >> 16) == f) | ((uint16_t)h.y == f) | ((uint16_t)(h.y >> 16) == f) |
            ((uint16_t)h.z == f) | ((uint16_t)(h.z >> 16) == f) | ((uint16_t)h.w == f);
 }
@@ -268,86 +213,32 @@ __device__ __forceinline__ uint32_t kid_dev_lookup(const KidDevDb &db, uint64_t 
 // ------------------------------------------------------------------ sliding-window minimum over a wavefront
 // 16-lane DPP rows double as the blocks of the van Herk / Gil-Werman scheme: with P = prefix
 // minimum and S = suffix minimum inside each row, min(a[p..p+15]) = min(S[p], P[p+15]).
-#ifndef KID_DPP_ASM
-#define KID_DPP_ASM 0 // 1: the scans as hand-written v_min_u32_dpp sequences (hipcc left the last step of a scan as mov + mov_dpp + min)
-#endif
 // (a lane whose DPP source lies outside its row is disabled for that instruction: it keeps its own value.  A VGPR written
 //  by a VALU instruction may be read through DPP two wait states later: s_nop 1 between dependent steps of ONE scan;
 //  kid_row_scans interleaves four scans instead)
 __device__ __forceinline__ uint32_t kid_row_prefix_min(uint32_t x)
 {
-#if KID_DPP_ASM
-    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(x));
-    return x;
-#else
     uint32_t t;
     t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x111, 0xF, 0xF, false); x = x < t ? x : t; // row_shr:1
     t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x112, 0xF, 0xF, false); x = x < t ? x : t;
     t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x114, 0xF, 0xF, false); x = x < t ? x : t;
     t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x118, 0xF, 0xF, false); x = x < t ? x : t;
     return x;
-#endif
 }
 __device__ __forceinline__ uint32_t kid_row_suffix_min(uint32_t x)
 {
-#if KID_DPP_ASM
-    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(x));
-    return x;
-#else
     uint32_t t;
     t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x101, 0xF, 0xF, false); x = x < t ? x : t; // row_shl:1
     t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x102, 0xF, 0xF, false); x = x < t ? x : t;
     t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x104, 0xF, 0xF, false); x = x < t ? x : t;
     t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x108, 0xF, 0xF, false); x = x < t ? x : t;
     return x;
-#endif
 }
 // prefix and suffix minima of two tiles at once: p0 = s0 = hashes of the first tile, p1 = s1 = those of the second
 __device__ __forceinline__ void kid_row_scans(uint32_t &p0, uint32_t &s0, uint32_t &p1, uint32_t &s1)
 {
-#if KID_DPP_ASM
-#define KID_SCAN4(n)                                                                                                    \
-    "v_min_u32_dpp %0, %0, %0 row_shr:" #n " row_mask:0xf bank_mask:0xf\n\t"                                            \
-    "v_min_u32_dpp %1, %1, %1 row_shl:" #n " row_mask:0xf bank_mask:0xf\n\t"                                            \
-    "v_min_u32_dpp %2, %2, %2 row_shr:" #n " row_mask:0xf bank_mask:0xf\n\t"                                            \
-    "v_min_u32_dpp %3, %3, %3 row_shl:" #n " row_mask:0xf bank_mask:0xf\n\t"
-    asm("s_nop 1\n\t" KID_SCAN4(1) KID_SCAN4(2) KID_SCAN4(4) KID_SCAN4(8) "s_nop 1" : "+v"(p0), "+v"(s0), "+v"(p1), "+v"(s1));
-#undef KID_SCAN4
-#else
     p0 = kid_row_prefix_min(p0); s0 = kid_row_suffix_min(s0);
     p1 = kid_row_prefix_min(p1); s1 = kid_row_suffix_min(s1);
-#endif
-}
-
-// ------------------------------------------------------------------ packed words of a read without the LDS crossbar
-// Pair kernel: lane 16 r + j of `w` holds packed word r + j of a read (see issue_words).  The 64 windows of tile K0/4
-// start at base sh + 16 K0 + lane: the lanes of row r want the words K0 + r + {0, 1, 2} of the read, or one further
-// (`hi`: the lane's window begins in the second word of its row) -- four row broadcasts (DPP row_newbcast: a VALU move)
-// and three selects, where ds_bpermute took three trips through the LDS crossbar per tile.  Those were what bounded the
-// loop: 16 of them per pair cost 0.21 of 0.87 ms (profiles/r02/ab_nobperm.txt).
-template <int N>
-__device__ __forceinline__ uint32_t kid_row_bcast(uint32_t w)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x150 + N, 0xF, 0xF, false); // row_newbcast:N
-}
-template <int K0>
-__device__ __forceinline__ void kid_row_words(uint32_t w, bool hi, uint64_t &A, uint64_t &B)
-{
-    const uint32_t r0 = kid_row_bcast<K0>(w), r1 = kid_row_bcast<K0 + 1>(w), r2 = kid_row_bcast<K0 + 2>(w), r3 = kid_row_bcast<K0 + 3>(w);
-    A = ((uint64_t)(hi ? r1 : r0) << 32) | (hi ? r2 : r1);
-    B = hi ? r3 : r2;
-}
-template <int K0>
-__device__ __forceinline__ uint64_t kid_row_words2(uint32_t w, bool hi) // two words: enough for an m-mer
-{
-    const uint32_t r0 = kid_row_bcast<K0>(w), r1 = kid_row_bcast<K0 + 1>(w), r2 = kid_row_bcast<K0 + 2>(w);
-    return ((uint64_t)(hi ? r1 : r0) << 32) | (hi ? r2 : r1);
 }
 
 // ------------------------------------------------------------------ taxonomy
@@ -391,9 +282,40 @@ __device__ __forceinline__ uint32_t kid_msca_climb(const KidDevDb &db, uint32_t 
 }
 
 // ------------------------------------------------------------------ base packing
-// 16 ASCII bases -> 32 bits of 2-bit codes (first base in the top bits) plus a
-// 16-bit mask of bytes that are not ACGTacgt (those reset the reference's
+// ASCII bases -> 2-bit codes plus a mask of the bytes that are not ACGTacgt (those reset the reference's
 // rolling window, newkmer_10nx.cpp:520-524).  4 bytes at a time, no per-byte branches.
+// kid_pack4: the 4 bases of one dword (byte 0 = first base) -> codes in bits 7:0 (first base in bits 7:6),
+// invalid flags in bits 3:0 of inv (bit j = byte j).
+__device__ __forceinline__ void kid_pack4(const uint32_t x, const uint32_t u_is_t, uint32_t &codes, uint32_t &inv)
+{
+    const uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u; // A,C,G,T -> 0,1,2,3 in every byte
+    codes = (c * 0x40100401u) >> 24;                        // byte0 -> bits 7:6 ... byte3 -> bits 1:0
+    // rebuild the upper-case letter each code stands for and compare
+    const uint32_t c0 = c & 0x01010101u, c1 = (c >> 1) & 0x01010101u, t = c0 & c1;
+    const uint32_t expect = 0x40404040u | (0x01010101u ^ t) | ((c0 ^ c1) << 1) | (c1 << 2) | (t << 4);
+    uint32_t diff = (x & 0xDFDFDFDFu) ^ expect;
+    if (u_is_t) diff &= ~t; // 'U' = 'T' ^ 1 and decodes to code 3
+    const uint32_t nz = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u;
+    inv = (((nz >> 7) * 0x00204081u) >> 21) & 0xFu;
+}
+// The same split in two for the pair loops, where almost no read has a base that is not ACGT: the codes and a word
+// `diff` that is non-zero in every byte that is not ACGTacgt(Uu) -- seven instructions (v_perm_b32 looks up the
+// letter a code stands for, v_dot4_u32_u8 gathers the four codes) --, and the 4-bit mask from `diff` when somebody
+// needs it.
+__device__ __forceinline__ uint32_t kid_codes4(const uint32_t x, const uint32_t u_is_t, uint32_t &diff)
+{
+    const uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;            // A,C,G,T -> 0,1,2,3 in every byte
+    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u, c); // byte j = "ACGT"[code of byte j]
+    diff = (x & 0xDFDFDFDFu) ^ expect;
+    if (u_is_t) diff &= ~(c & (c >> 1) & 0x01010101u);                 // 'U' = 'T' ^ 1 and decodes to code 3
+    return __builtin_amdgcn_udot4(c, 0x01041040u, 0u, false);          // byte0 -> bits 7:6 ... byte3 -> bits 1:0
+}
+__device__ __forceinline__ uint32_t kid_inv4(const uint32_t diff)
+{
+    const uint32_t nz = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u;
+    return (((nz >> 7) * 0x00204081u) >> 21) & 0xFu;
+}
+// 16 bases -> one packed word (first base in the top bits) + 16-bit mask
 __device__ __forceinline__ void kid_pack16(const uint4 v, const uint32_t u_is_t, uint32_t &codes, uint32_t &inv)
 {
     const uint32_t in[4] = {v.x, v.y, v.z, v.w};
@@ -401,47 +323,36 @@ __device__ __forceinline__ void kid_pack16(const uint4 v, const uint32_t u_is_t,
     inv = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const uint32_t x = in[q];
-        const uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u; // A,C,G,T -> 0,1,2,3 in every byte
-        codes = (codes << 8) | ((c * 0x40100401u) >> 24);       // byte0 -> bits 7:6 ... byte3 -> bits 1:0
-        // rebuild the upper-case letter each code stands for and compare
-        const uint32_t c0 = c & 0x01010101u, c1 = (c >> 1) & 0x01010101u, t = c0 & c1;
-        const uint32_t expect = 0x40404040u | (0x01010101u ^ t) | ((c0 ^ c1) << 1) | (c1 << 2) | (t << 4);
-        uint32_t diff = (x & 0xDFDFDFDFu) ^ expect;
-        if (u_is_t) diff &= ~t; // 'U' = 'T' ^ 1 and decodes to code 3
-        const uint32_t nz = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u;
-        inv |= ((((nz >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * q);
+        uint32_t c8, i4;
+        kid_pack4(in[q], u_is_t, c8, i4);
+        codes = (codes << 8) | c8;
+        inv |= i4 << (4 * q);
     }
 }
 
 // ------------------------------------------------------------------ batch preparation
-// [start, stop] -> descriptor; the range checks the reference leaves to string::at() happen here
-// (runs after kid_pack_kernel: `inval` is the packed invalid-mask image of the batch)
-// what a launch of the classify kernels finds in the set's device argument block: its share of the descriptors and of the
-// result array; `arm`: the device-clock bracket of the batch (kid_sample_kernel_time_device) -- bank the interval of the
-// batch before, arm the slots for this one.  stats[30] = first start, stats[31] = last end (100 MHz ticks)
-__device__ __forceinline__ void kid_rebase(KidRareArgs *rare, const KidReadDesc *desc, uint32_t *out_final, unsigned long long *stats, int arm)
+// What a launch of the classify kernels finds in its device argument block: its share of the descriptors (or the fixed
+// layout) and of the result array.  Set in classify-stream order.
+__device__ __forceinline__ void kid_rebase(KidRareArgs *rare, const KidReadDesc *desc, uint32_t *out_final, unsigned long long read0,
+                                           uint32_t fixed_len, int32_t fixed_nk)
 {
     if (threadIdx.x == 0) {
         rare->desc = desc;
         rare->out_final = out_final;
-        if (arm) {
-            const unsigned long long a = stats[30], z = stats[31];
-            if (z > a) { stats[6] += z - a; stats[7] += 1; }
-            stats[30] = ~0ull;
-            stats[31] = 0;
-        }
+        rare->read0 = read0;
+        rare->fixed_len = fixed_len;
+        rare->fixed_nk = fixed_nk;
     }
-    if (threadIdx.x < KID_DYN_SHARDS) rare->dyn[threadIdx.x * 16u] = 0;
 }
 
+// [start, stop] -> descriptor; the range checks the reference leaves to string::at() happen here
 __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, unsigned long long *stats, KidRareArgs *rare, uint32_t seq,
-                                   const uint16_t *inval, uint32_t long_cut, int rebase)
+                                   uint32_t long_cut, int rebase)
 {
-    // (descriptor / result pointers, the chunk counters and the device-clock stamps of the batch are set in classify-stream
-    //  order: by kid_rebase_kernel when this kernel may run while the batch before is being classified, else -- `rebase`,
-    //  same stream -- right here for the batch's first launch: one launch and its gap less per step)
-    if (rebase && blockIdx.x == 0) kid_rebase(rare, desc, b.out_final, stats, 1);
+    // (the launch's descriptor / result pointers are set in classify-stream order: by kid_rebase_kernel when this kernel
+    //  may run while the batch before is being classified, else -- `rebase`, same stream -- right here for the batch's
+    //  first launch: one launch and its gap less per batch)
+    if (rebase && blockIdx.x == 0) kid_rebase(rare, desc, b.out_final, 0ull, 0u, 0);
     uint32_t bad = 0, mx = 0;
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < b.n; r += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t off;
@@ -460,19 +371,10 @@ __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, u
         if (s0 > e0) nk = 0;
         d.first_base = off + (uint64_t)(s0 > 0 ? s0 : 0);
         d.n_kmers = (int32_t)(nk > 0x7FFFFFFF ? 0x7FFFFFFF : nk);
-        // a record the host hands to the long-record kernels (kid_long_hits_kernel / kid_long_fold_kernel): the classify
+        d.pad = 0;
+        // a record that goes to the long-record kernels (kid_long_hits_kernel / kid_long_fold_kernel): the classify
         // kernels see a read without k-mers (counted under target 0 until the fold corrects that)
         if (long_cut && nk > (int64_t)long_cut) d.n_kmers = 0;
-        // pad bit 0: "some base of the read may reset a window" -- short reads are checked against the packed
-        // mask (their 16-base chunks, a little more than the classified range), so that the classify kernel
-        // need not fetch the mask of a clean read; longer reads are simply called dirty
-        d.pad = d.n_kmers > 0 ? 1u : 0u;
-        if (d.n_kmers > 0 && d.n_kmers <= 256 && inval) {
-            const uint64_t c0 = d.first_base >> 4, c1 = (d.first_base + (uint64_t)d.n_kmers + (uint64_t)k - 2u) >> 4;
-            uint32_t any = 0;
-            for (uint64_t c = c0; c <= c1; c++) any |= inval[c];
-            d.pad = any ? 1u : 0u;
-        }
         desc[r] = d;
         if (d.n_kmers > 0 && (uint32_t)d.n_kmers > mx) mx = (uint32_t)d.n_kmers;
     }
@@ -494,13 +396,17 @@ __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, u
     if (bad) atomicAdd(&stats[4], (unsigned long long)bad);
 }
 
-// a batch classified in several launches: the next launch's share of the descriptors and of the result array
-__global__ void kid_rebase_kernel(KidRareArgs *rare, const KidReadDesc *desc, uint32_t *out_final, unsigned long long *stats, int arm)
+// Sets a launch's argument block without kid_prepare_kernel: the later launches of a batch classified in several, and
+// every launch of a fixed-layout batch (no descriptors: the host knows the one read length; batch_max = (seq << 32) | k-mers)
+__global__ void kid_rebase_kernel(KidRareArgs *rare, const KidReadDesc *desc, uint32_t *out_final, unsigned long long read0,
+                                  uint32_t fixed_len, int32_t fixed_nk, unsigned long long batch_max)
 {
-    kid_rebase(rare, desc, out_final, stats, arm);
+    kid_rebase(rare, desc, out_final, read0, fixed_len, fixed_nk);
+    if (threadIdx.x == 0 && batch_max) rare->batch_max = batch_max;
 }
 
-// ASCII -> 2 bits per base + invalid mask for the whole batch buffer, 16 bases per lane
+// ASCII -> 2 bits per base + invalid mask for a whole batch buffer, 16 bases per lane: the packed image the
+// long-record kernels index by position (kid_long_hits_kernel); the classify kernels pack in registers
 __global__ void kid_pack_kernel(const uint8_t *bases, uint64_t nchunks, uint32_t u_is_t, uint32_t *codes, uint16_t *inval)
 {
     for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < nchunks; c += (uint64_t)gridDim.x * blockDim.x) {
@@ -542,45 +448,19 @@ struct KidGroup {      // a group of U*64 windows between its two halves
 // batch is for when it knows the longest read, else all three: the others return at once.  Separate
 // kernels, because each loop wants all 64 vector registers of an 8-waves-per-SIMD kernel for itself.
 template <int U, bool ROWS, bool HIST, bool MINLOC, int KFIX, int PAIRK>
-__global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_classify_kernel(const KidDevDb db, const KidPacked b, const KidSampleDev s,
+__global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(const KidDevDb db, const KidInput b, const KidSampleDev s,
                                                             const uint32_t hist_words,
                                                             const KidReadDesc *__restrict__ const descs,
                                                             const KidRareArgs *__restrict__ const rare)
 {
     static_assert(!PAIRK || (MINLOC && U == 2), "the pair loop exists for the minimizer-localised table, two windows per lane");
-    if (MINLOC && KID_PAIRS) { // wave-uniform, before anything else
+    if (MINLOC) { // wave-uniform, before anything else
         const uint32_t longest = (uint32_t)rare->batch_max;
         const int mode = longest <= (uint32_t)(U * 64) ? 1 : longest <= (uint32_t)(2 * U * 64) ? 2 : 0;
         if (mode != PAIRK) return;
     }
+    // the launch on the device's own clock (kid_sample_kernel_time_device): first workgroup to start ... last one to end
     if (threadIdx.x == 0) atomicMin(&s.stats[30], (unsigned long long)__builtin_amdgcn_s_memrealtime());
-#ifdef KID_WAVEPROF // development aid: when do the waves of a launch pass their 64th, 128th ... read, and when do they end?
-    unsigned long long wp_t0 = __builtin_amdgcn_s_memrealtime(), wp_prev = wp_t0;
-    uint32_t wp_q = 0;
-#endif
-#if defined(KID_PRIO) && KID_PRIO > 0
-    // experiment: the SIMD's issue arbitration prefers its older waves (those finish first, the rest of the kernel
-    // runs at a falling occupancy); 1: the second-dispatched half of a workgroup's waves gets static priority 1,
-    // 2: priority by wave number within its SIMD pair and workgroup parity
-    if (PAIRK == 1) {
-        const uint32_t w8 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        if (KID_PRIO == 1) { if (w8 >= 4u) __builtin_amdgcn_s_setprio(1); }
-        else if (KID_PRIO == 2) { if (((w8 >> 2) ^ blockIdx.x) & 1u) __builtin_amdgcn_s_setprio(1); }
-        else if (KID_PRIO == 3) { if (w8 >= 4u) __builtin_amdgcn_s_setprio(3); }
-        else if (KID_PRIO == 4) { // the later a workgroup was dispatched, the higher its priority (blockIdx / CUs = its age class)
-            const uint32_t cls = blockIdx.x >> 8;
-            if (cls == 1u) __builtin_amdgcn_s_setprio(1);
-            else if (cls == 2u) __builtin_amdgcn_s_setprio(2);
-            else if (cls >= 3u) __builtin_amdgcn_s_setprio(3);
-        }
-        else if (KID_PRIO == 5) { // the same, inverted (control)
-            const uint32_t cls = blockIdx.x >> 8;
-            if (cls == 0u) __builtin_amdgcn_s_setprio(3);
-            else if (cls == 1u) __builtin_amdgcn_s_setprio(2);
-            else if (cls == 2u) __builtin_amdgcn_s_setprio(1);
-        }
-    }
-#endif
     // (descs == b.desc, passed once more as a restrict-qualified argument: the wave-uniform
     //  descriptor loads then become scalar loads, which stay in flight until first use)
     extern __shared__ uint32_t kid_smem[];
@@ -619,18 +499,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
     unsigned long long *const WL = reinterpret_cast<unsigned long long *>(WC);
     if (lane < 4) WC[lane] = 0;
     uint32_t pend_t = 0, pend_n = 0;       // !HIST: run-length buffer in front of the global gcount atomics
-#ifdef KID_ABLATE
-    uint32_t sink = 0;
-#endif
 
-#ifdef KID_PROFILE // development aid: cycles of a wave per phase of the sequential read loop
-    unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
-#define KID_TICK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[i] += t_ - prof_t; prof_t = t_; } while (0)
-#define KID_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#else
-#define KID_TICK(i) do { } while (0)
-#define KID_DRAIN() do { } while (0)
-#endif
     // ---- 1. stage one packed segment in a strip; returns "no base of it resets a window" (wave-uniform)
     auto stage = [&](uint32_t *W, const uint32_t codes, const uint32_t inv) -> bool {
         uint32_t *IM = W + 66;
@@ -648,35 +517,22 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
     auto group_front = [&](const uint32_t *W, const uint32_t sh, const uint32_t nb, const uint32_t segk, const uint32_t t0,
                            const bool seg_clean, KidGroup<U> &g, uint32_t &n_bad, const bool issue_loads = true,
                            const uint32_t wcodes = 0, const uint32_t winv = 0) {
-        // W == nullptr (pair kernel): no LDS strip; lane c holds packed word c and mask c of the read in
-        // (wcodes, winv) and a window fetches its three words with ds_bpermute -- one LDS round trip
-        // instead of write + barrier + read.  Needs the whole read inside 64 words, which a group is.
+        // W == nullptr (pair kernels): no LDS strip; the lanes hold the read's packed words and masks in (wcodes, winv)
+        // -- word c of the read in the LW = 4 (pair kernel) or 2 (duo kernel) lanes that loaded its 16 bases, see
+        // pack_lanes -- and a window fetches its three words with ds_bpermute: one LDS round trip instead of
+        // write + barrier + read.  Needs the whole read inside 64 / LW words, which one (two) group(s) of a read are.
         const bool direct = (W == nullptr);
+        constexpr uint32_t LWS = PAIRK == 1 ? 2u : 1u; // log2 of the lanes per word
         auto word = [&](const uint32_t idx) -> uint32_t {
-#ifdef KID_ABLATE_BPERM // timing experiment only (wrong k-mers): how much of the front half is the LDS crossbar?
-            if (direct) return (wcodes ^ idx) * 0x9E3779B1u;
-#endif
-            return direct ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)wcodes) : W[idx];
+            return direct ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << (2u + LWS)), (int)wcodes) : W[idx];
         };
         auto mask32 = [&](const uint32_t idx) -> uint32_t { // invalid-mask bits of bases 32 idx .. 32 idx + 31
             if (!direct) return (W + 66)[idx];
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 3), (int)winv);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx << 3) + 4u), (int)winv);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << (3u + LWS)), (int)winv);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx << (3u + LWS)) + (4u << LWS)), (int)winv);
             return (lo & 0xFFFFu) | (hi << 16);
         };
-        // pair kernel: the words come row-wise (kid_row_words); the windows of lanes past the read's end then hold the bases
-        // that follow it in the packed image -- no k-mer of the read looks at their m-mers
-        const bool rowmode = direct && PAIRK == 1 && KID_ROW_WORDS;
-        const bool hiw = (lane & 15u) + sh >= 16u;
         uint32_t P[U + 1], S[U]; // minloc: row prefix / suffix minima of the hashed m-mers
-#ifdef KID_ABLATE_EXTRA_VALU // timing experiment only: how sensitive is the loop to its VALU instruction count?
-        {
-            uint32_t dummy = lane;
-#pragma unroll
-            for (int e = 0; e < KID_ABLATE_EXTRA_VALU; e++) asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(dummy));
-            asm volatile("" : : "v"(dummy));
-        }
-#endif
         const uint32_t pmax = sh + nb - (uint32_t)mlen; // last m-mer start inside the segment
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -685,16 +541,10 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             // lanes past the last k-mer still hash their m-mer (the windows of earlier lanes reach
             // 14 positions ahead), clamped to the last one that lies inside the segment
             uint32_t p = sh + i;
-            if (!rowmode) p = MINLOC ? (p < pmax ? p : pmax) : sh + (i < segk ? i : 0u);
+            p = MINLOC ? (p < pmax ? p : pmax) : sh + (i < segk ? i : 0u);
             const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
-            uint64_t A, B;
-            if (rowmode) {
-                if (u == 0) kid_row_words<0>(wcodes, hiw, A, B);
-                else kid_row_words<4>(wcodes, hiw, A, B);
-            } else {
-                A = ((uint64_t)word(w0) << 32) | word(w0 + 1);
-                B = word(w0 + 2);
-            }
+            const uint64_t A = ((uint64_t)word(w0) << 32) | word(w0 + 1);
+            const uint64_t B = word(w0 + 2);
             const uint64_t x = (A << o2) | ((B << o2) >> 32);
             const uint64_t keyF = x >> (64 - 2 * k);
             // one reversal of the 32-base window serves both reverse complements: base j of the window
@@ -711,39 +561,31 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             g.key[u] = keyF < keyR ? keyF : keyR; // newkmer_10nx.cpp:528
             if (!MINLOC) g.hlo[u] = (uint32_t)kid_fmix64(g.key[u]) & db.slot_mask;
             g.act[u] = valid;
-            if (MINLOC && !KID_ABLATE_NOMIN) {
+            if (MINLOC) {
                 const uint32_t h = kid_mmer_hash2((uint32_t)(x >> (64 - 2 * mlen)), (uint32_t)nrv & (0xFFFFFFFFu >> (32 - 2 * mlen)));
                 P[u] = h;
                 S[u] = h;
             }
         }
-        if (MINLOC && !KID_ABLATE_NOMIN) {
+        if (MINLOC) {
             if constexpr (U == 2) kid_row_scans(P[0], S[0], P[1], S[1]);
             else {
 #pragma unroll
                 for (int u = 0; u < U; u++) { P[u] = kid_row_prefix_min(P[u]); S[u] = kid_row_suffix_min(S[u]); }
             }
         }
-#if defined(KID_ABLATE) && KID_ABLATE >= 2
-        if (false) {
-#else
         if (MINLOC) {
-#endif
             g.fpp = 0;
 #pragma unroll
             for (int u = 0; u < U; u++) g.fpp |= kid_key_fp(g.key[u]) << (16 * u);
             // the win-1 m-mers behind the last k-mer of the group -- if any window of the group reaches that
             // far (wave-uniform: a 100-bp read ends inside the group, m-mers and all)
             P[U] = 0xFFFFFFFFu;
-#ifdef KID_ABLATE_NOTAIL // timing experiment only (wrong minimizers for the last windows of a read)
-            if (false) {
-#else
             if (segk + win - 1u > t0 + (uint32_t)U * 64u) {
-#endif
                 uint32_t p = sh + t0 + (uint32_t)U * 64u + lane;
-                if (!rowmode) p = p < pmax ? p : pmax;
+                p = p < pmax ? p : pmax;
                 const uint32_t w0 = p >> 4, o2 = (p & 15u) * 2u;
-                const uint64_t A = rowmode ? kid_row_words2<4 * U>(wcodes, hiw) : ((uint64_t)word(w0) << 32) | word(w0 + 1);
+                const uint64_t A = ((uint64_t)word(w0) << 32) | word(w0 + 1);
                 P[U] = kid_row_prefix_min(kid_mmer_hash((uint32_t)((A << o2) >> (64 - 2 * mlen)), mlen));
             }
             // ... and their minimum over every window a[p..p+win-1].  With q = p mod 16: the window
@@ -982,9 +824,6 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
     // i_now: number of the newest queued read (all are within 63 of it); open_tag: a read that may still get
     // entries (general loops, between the groups of a read) -- its run is folded but not committed
     auto resolve_all = [&](const uint32_t i_now, const uint32_t open_tag) {
-#ifdef KID_PROFILE
-        const unsigned long long rt0 = __builtin_amdgcn_s_memtime();
-#endif
         // (the pair kernel never leaves a read open between calls: its carry lives and dies in here)
         uint32_t ctag = PAIRK == 1 ? 0xFFFFFFFFu : cur_tag, final_t = PAIRK == 1 ? 0u : final_c, vfrow = PAIRK == 1 ? 0u : vfrow_c;
         auto commit_tag = [&](const uint32_t tag, const uint32_t f) {
@@ -995,7 +834,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             const bool valid = lane < n;
             uint32_t klo = 0, khi = 0, ln = 0, tag = 0;
             if (valid) { klo = CQ_klo[base + lane]; khi = CQ_khi[base + lane]; ln = CQ_lw[base + lane]; tag = CQ_tag[base + lane]; }
-            const bool verified = KID_EARLY_CAND && (tag & 0x80u) != 0; // {target, entry ordinal} fetched when the header came in
+            const bool verified = (tag & 0x80u) != 0; // {target, entry ordinal} fetched when the header came in
             tag &= 63u;
             // the header once more (the queue keeps only the line: working out the candidates at
             // queueing time would cost the hot loop ~45 instructions per read with a match)
@@ -1037,11 +876,8 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             }
             uint4 row = make_uint4(0, 0, 0, 0);
             if (tgt > 0) {
-#ifndef KID_ABLATE_NOFOLD // timing experiments only (wrong counters): what do the parts of hit handling cost?
                 if (ROWS) row = rare->rows[tgt];
-#endif
             }
-#ifndef KID_ABLATE_NOSEEN
             {
                 // kmer_seen (:596-600).  The entries of a pass are in read and window order, and consecutive k-mers of a
                 // genome carry consecutive entry ordinals when the database lists them in genome order (the reference's
@@ -1053,7 +889,6 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
                 const bool sb = tgt > 1;
                 const uint32_t word = sb ? slot >> 5 : 0xFFFFFFF0u + (lane & 15u); // (no two neighbours without a hit alike)
                 uint32_t bits = sb ? 1u << (slot & 31u) : 0u;
-#if KID_SEEN_COMBINE
 #define KID_SEEN_STEP(CTRL)                                                                                                    \
                 {                                                                                                               \
                     const uint32_t w_ = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)word, CTRL, 0xF, 0xF, false); \
@@ -1064,11 +899,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
 #undef KID_SEEN_STEP
                 const uint32_t w_next = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)word, 0x101, 0xF, 0xF, false); // row_shl:1
                 if (sb && w_next != word) kid_atomic_or_nowait(&rare->seen[word], bits);
-#else
-                if (sb) kid_atomic_or_nowait(&rare->seen[word], bits);
-#endif
             }
-#endif
             const uint64_t hitm = __ballot(tgt > 0);
             if (hitm && lane == 0) atomicAdd(&WC[2], (uint32_t)__popcll(hitm));
             // Fold read by read, one lane per read: entries of a read are neighbours (a change of tag
@@ -1092,12 +923,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
                 }
             }
             if (ctag != 0xFFFFFFFFu && (uint32_t)__builtin_amdgcn_readfirstlane((int)tag) != ctag) commit_tag(ctag, final_t);
-#ifdef KID_ABLATE_NOFOLD
-            if (head) f = tgt;
-            if (false) {
-#else
             if (__popcll(hm) <= 6) {
-#endif
                 // Few, long runs (reads with many hits): the runs in turn, all entries of a run at once.
                 // Every lane works out the step its own entry would make from the run's current result;
                 // entries up to the first one that changes the result leave it as it is -- which is all
@@ -1135,11 +961,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
                     if (lane == (uint32_t)h) { f = uf; fr = ufr; }
                 }
             } else
-#ifdef KID_ABLATE_NOFOLD
-            for (uint32_t t = 0; false; t++) {
-#else
             for (uint32_t t = 0; __ballot(head && t < len) != 0; t++) {
-#endif
                 const int src = (int)(((lane + t) & 63u) << 2);
                 const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)tgt);
                 uint4 rx;
@@ -1187,9 +1009,6 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
         // a real s_waitcnt (not inline assembly): hipcc's waitcnt pass then knows that none of ITS loads is
         // pending when this rare path rejoins the loop, and does not drain vmcnt at the top of every trip
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), expcnt and lgkmcnt untouched
-#ifdef KID_PROFILE
-        prof[9] += __builtin_amdgcn_s_memtime() - rt0; // (also contained in the phase that called)
-#endif
     };
     // header test of one group of a read; its unsettled lookups go to the queue.  false: there were none
     auto back_deferred = [&](const KidGroup<U> &g, const uint32_t i) -> bool {
@@ -1211,9 +1030,9 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             // (only while hits are sparse: with many flagged lookups per tile the resolver runs every few reads, finds the
             //  lines still in the L2, and the wait for the candidate here would cost more than its second fetch --
             //  builder-shaped database, 15.9 hits per read: 2.15 vs 1.92 ms per 1 M pairs, profiles/r02/clumped_ec.txt)
-            const bool early = KID_EARLY_CAND && (uint32_t)__popcll(qm) <= KID_EARLY_MAX && qn < KID_EARLY_QN;
+            const bool early = (uint32_t)__popcll(qm) <= KID_EARLY_MAX && qn < KID_EARLY_QN;
             const uint32_t cm = (early && mm[u]) ? kid_hdr_cand(g.hd[u], fp[u]) : 0u;
-            if (KID_EARLY_CAND) { // (cells read: one add for the wave)
+            { // (cells read: one add for the wave)
                 const uint64_t cmb = __ballot(cm != 0);
                 if (cmb && lane == 0) atomicAdd(&WC[3], (uint32_t)__popcll(cmb));
             }
@@ -1238,8 +1057,8 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
     // ---- a whole read of any length on its own, given its descriptor and its first packed segment.
     // `prefetch` issues the loads for the reads behind this one; it is called right after this read's
     // first header loads went out (not before the loops: the compiler drains vmcnt in front of a loop)
-    auto process_read = [&](const uint64_t r, const uint32_t i, const uint64_t first, const int64_t nk, const uint32_t st_codes,
-                            const uint32_t st_inv, auto &&prefetch) {
+    auto process_read = [&](const uint64_t r, const uint32_t i, const uint64_t first, const int64_t nk, const kid_u4 st_raw,
+                            auto &&prefetch) {
         bool prefetched = false, had = false;
         uint32_t final_t = 0;
         uint32_t vfrow = 0, n_bad = 0;
@@ -1250,14 +1069,11 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             const uint64_t c0 = b0 >> 4;
             const uint32_t sh = (uint32_t)(b0 & 15ull);
             const uint32_t nchunks = (sh + nb + 15u) >> 4; // <= 64
-            uint32_t codes = st_codes, inv = st_inv;
-            if (seg != 0) { // long reads: later segments are fetched on the spot
-                codes = 0; inv = 0;
-                if (lane < nchunks) {
-                    codes = b.codes[c0 + lane];
-                    inv = b.inval[c0 + lane];
-                }
-            }
+            kid_u4 raw = st_raw;
+            if (seg != 0) // long reads: later segments are fetched on the spot (lanes past the segment: its first chunk again)
+                raw = *reinterpret_cast<const kid_u4 *>(b.bases + 16ull * (c0 + (lane < nchunks ? lane : 0u)));
+            uint32_t codes, inv;
+            kid_pack16(make_uint4(raw.x, raw.y, raw.z, raw.w), db.u_is_t, codes, inv);
             const bool seg_clean = stage(WA, codes, inv);
             for (uint32_t t0 = 0; t0 < segk; t0 += U * 64u) {
                 KidGroup<U> g;
@@ -1283,15 +1099,19 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
 
     auto fetch_desc = [&](uint32_t r, KidReadDesc &d) {
         d.first_base = 0; d.n_kmers = 0; d.pad = 0;
-        if (r < (uint32_t)b.n) d = descs[r];
+        if (r < (uint32_t)b.n) {
+            if (b.desc) d = descs[r];
+            else { d.first_base = (rare->read0 + r) * (unsigned long long)rare->fixed_len; d.n_kmers = rare->fixed_nk; } // fixed layout
+        }
     };
-    auto fetch_words = [&](const KidReadDesc &d, uint32_t &codes, uint32_t &inv) {
-        // unconditional (the scratch arrays are padded by 64 entries): a fixed number of loads keeps the
-        // compiler's vmcnt bookkeeping exact, so the waits for older loads do not drain these
-        // wave-uniform base + 32-bit lane offset: the scalar-base addressing form, no 64-bit vector addresses
-        const uint64_t w0 = d.first_base >> 4;
-        codes = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(b.codes + w0) + lane * 4u);
-        inv = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(b.inval + w0) + lane * 2u);
+    // the first segment of a read as text: lane c asks for the 16 bytes of chunk c.  Unconditional -- a fixed number of
+    // loads keeps the compiler's vmcnt bookkeeping exact, so the waits for older loads do not drain these -- but never
+    // beyond the chunk that holds the segment's last base: the lanes past it ask for its first chunk again (their words
+    // are never looked at).  Wave-uniform base + 32-bit lane offset: the scalar-base addressing form
+    auto fetch_words = [&](const KidReadDesc &d, kid_u4 &raw) {
+        const uint32_t segk = d.n_kmers > KID_SEG_KMERS ? (uint32_t)KID_SEG_KMERS : d.n_kmers > 0 ? (uint32_t)d.n_kmers : 0u;
+        const uint32_t nchunks = (((uint32_t)d.first_base & 15u) + segk + (uint32_t)k - 1u + 15u) >> 4;
+        raw = *reinterpret_cast<const kid_u4 *>(reinterpret_cast<const char *>(b.bases + 16ull * (d.first_base >> 4)) + (lane < nchunks ? lane : 0u) * 16u);
     };
     auto uniform64 = [](uint64_t v) {
         return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
@@ -1299,47 +1119,27 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
     // ---- phase 1: every read of one segment (<= 960 k-mers: all short-read data).  Longer ones are
     // left to phase 2, so that their loop nest and 64-bit bookkeeping stay out of this loop's registers
     bool any_long = false;
-    auto short_read = [&](const uint32_t r, const uint32_t i, const uint64_t first, const int32_t nk, const uint32_t st_codes,
-                          const uint32_t st_inv, auto &&prefetch) {
+    auto short_read = [&](const uint32_t r, const uint32_t i, const uint64_t first, const int32_t nk, const kid_u4 st_raw,
+                          auto &&prefetch) {
         if (nk > KID_SEG_KMERS) { any_long = true; rb_skip |= 1ull << (i & 63u); prefetch(); return; }
         bool prefetched = false, had = false;
         uint32_t final_t = 0;
         uint32_t vfrow = 0, n_bad = 0;
         if (nk > 0) {
             const uint32_t sh = (uint32_t)first & 15u, segk = (uint32_t)nk, nb = segk + (uint32_t)k - 1;
-            KID_TICK(0);
-            KID_DRAIN();
-            KID_TICK(1); // waiting for the prefetched words
-#if defined(KID_ABLATE) && KID_ABLATE >= 4 // timing experiments only (results are wrong): no staging either
-            const bool seg_clean = true;
-            sink ^= st_codes ^ st_inv;
-#else
+            uint32_t st_codes, st_inv;
+            kid_pack16(make_uint4(st_raw.x, st_raw.y, st_raw.z, st_raw.w), db.u_is_t, st_codes, st_inv);
             const bool seg_clean = stage(WA, st_codes, st_inv);
-#endif
             for (uint32_t t0 = 0; t0 < segk; t0 += U * 64u) {
                 KidGroup<U> g;
-#if defined(KID_ABLATE)
-                // 1: front half without the header loads, no back half; 2: (see group_front) keys only; 3+: no front half
-                if (KID_ABLATE <= 2) {
-                    group_front(WA, sh, nb, segk, t0, seg_clean, g, n_bad, false);
-                    sink ^= g.hlo[0] ^ g.hlo[1] ^ (uint32_t)g.key[0] ^ (uint32_t)g.key[1] ^ (uint32_t)(g.key[0] >> 32) ^ (uint32_t)(g.key[1] >> 32);
-                }
-                if (!prefetched) { prefetch(); prefetched = true; }
-                continue;
-#endif
                 group_front(WA, sh, nb, segk, t0, seg_clean, g, n_bad);
                 if (!prefetched) { prefetch(); prefetched = true; }
-                KID_TICK(2); // stage + front half
-                KID_DRAIN();
-                KID_TICK(3); // waiting for the headers
                 if constexpr (MINLOC) {
                     had |= back_deferred(g, i);
                     if (qn >= KID_CQ_FLUSH) resolve_all(i, i & 63u); // the read stays open: more groups may follow
                 } else {
                     group_back(g, final_t, vfrow);
                 }
-                KID_DRAIN();
-                KID_TICK(4); // back half incl. hit path
             }
             __builtin_amdgcn_wave_barrier(); // strip is rewritten by the next read
         }
@@ -1350,10 +1150,8 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             finish_read(r, final_t, (nk > 0 ? (uint32_t)nk : 0u) - n_bad);
         }
         if (!prefetched) prefetch();
-        KID_TICK(5);
     };
     uint32_t reads_done = gw < b.n ? (uint32_t)((b.n - gw + nw - 1) / nw) : 0u; // the wave's strided share (the pair kernel counts its own)
-#if KID_PAIRS
     // ---- batches whose reads all fit one group (<= U*64 k-mers: Illumina reads): hand-pipelined pairs.
     // A wave is a chain of dependent round trips (strip, header, hit cell, ancestor row) that eight waves
     // per SIMD do not cover, so two reads travel together: front half of A, front half of B (four header
@@ -1364,9 +1162,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
     // return in order, and anything the compiler issues in between (hit cells, atomics, the out_final
     // store) only makes an explicit count stricter than needed.
     if constexpr (PAIRK != 0) {
-        uint32_t cnt = gw < b.n ? (uint32_t)((b.n - gw + nw - 1) / nw) : 0u; // reads of this wave: gw + i nw
-        uint32_t duo_first = gw32, duo_stride = nw32;
-#if KID_TAPER
+        uint32_t cnt = 0, duo_first = 0; // duo kernel: the wave's reads are duo_first .. duo_first + cnt - 1
         if (PAIRK == 2) {
             // the duo kernel's waves take one contiguous range of reads each, in the pair kernel's shrinking shares (see
             // switch_block): KID_TAPER units of reads per wave in the first half of the workgroups, one in the second
@@ -1377,88 +1173,111 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             const uint64_t ufirst = (uint64_t)wpb * (wg < half ? KID_TAPER * wg : KID_TAPER * half + (wg - half)) + (uint64_t)wib * mine;
             const uint64_t f64 = ufirst * unit;
             duo_first = f64 < nb2 ? (uint32_t)f64 : nb2;
-            duo_stride = 1u;
             cnt = nb2 - duo_first < mine * unit ? nb2 - duo_first : mine * unit;
             rd_first = duo_first;
             rd_stride = 1u;
             reads_done = cnt;
         }
-#endif
-        const uint32_t lane4 = lane * 4u;
-        const uint32_t lane4row = ((lane >> 4) + (lane & 15u)) * 4u; // byte offset of the word a lane holds when words come row-wise
-        // descriptors, 64 at a time: lane l holds the one of read number blk + l of this wave -- the low word
-        // of first_base, and its high word (< 2^16: a batch is smaller than 2^48 bytes) with n_kmers (<= 128
-        // in this kernel) above it
-        // A wave works through SEGMENTS of reads: read j of a segment is read seg_first + j seg_stride of the batch and
-        // has the wave-local number seg_seq0 + j (tags and result slots go by wave-local numbers, which simply run on
-        // from segment to segment).  The duo kernel has one segment: the wave's strided share of the batch.
-        uint32_t blk = 0, dv_lo = 0, dv_hn = 0;
-        uint32_t seg_first = duo_first, seg_stride = duo_stride, seg_seq0 = 0, seg_end = cnt;
-        auto load_block = [&]() {
-            const uint32_t sq = blk + lane; // wave-local number
-            dv_lo = 0; dv_hn = 0;
-            if (sq < seg_end) {
-                const uint32_t rr = seg_first + (sq - seg_seq0) * seg_stride;
-                const KidReadDesc d = static_cast<const KidReadDesc *>(rare->desc)[rr];
-                dv_lo = (uint32_t)d.first_base;
-                dv_hn = ((uint32_t)(d.first_base >> 32) & 0xFFFFu) | ((d.n_kmers > 0 ? (uint32_t)d.n_kmers : 0u) << 16) | ((d.pad & 1u) << 31);
-                if (PAIRK == 1) RG[sq & 127u] = rr;
-            }
+        // ---- the read text.  A read of the pair kernel (<= 128 k-mers, k <= 31, behind a shift of <= 15 bases) lies
+        // in the first 176 bytes from its 16-byte boundary, one of the duo kernel (<= 256 k-mers) in the first 304:
+        // lane l loads bytes [BPL l, BPL l + BPL) of them -- BPL = 4 bases per lane (pair) or 8 (duo), one load
+        // instruction per read -- and only the lanes whose bytes hold bases of the read ask (exec is narrowed inside the
+        // statement: the compiler must not see a load in a branch of its own).  Nothing beyond the dword that holds the
+        // read's last classified base is touched, so the caller's buffer needs no padding beyond its own 16 bytes.
+        constexpr uint32_t BPL = PAIRK == 1 ? 4u : 8u;
+        typedef typename std::conditional<PAIRK == 1, uint32_t, kid_u2>::type Raw;
+        const uint32_t lane_off = lane * BPL;
+        auto ask_lanes = [&](const uint32_t sh, const uint32_t nk) -> uint64_t { // the lanes that hold bases of a read (never none: a load always goes out)
+            const uint32_t nl = nk ? (sh + nk + (uint32_t)k - 1u + BPL - 1u) / BPL : 1u; // <= 44 (pair), 38 (duo)
+            return (1ull << nl) - 1ull;
         };
-        auto issue_words = [&](const uint32_t idx, uint32_t &c, uint32_t &iv) {
-            const uint32_t hn = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)idx); // [15:0] first_base >> 32, [30:16] n_kmers, [31] may hold a masked base
-            const uint64_t w0 = (((uint64_t)(hn & 0xFFFFu) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)idx)) >> 4;
-#ifdef KID_ABLATE_WORDS // timing experiment only: the packed words always come from the same few cache lines
-            const uint32_t *const pc = b.codes + (w0 & 1023u);
-            const uint16_t *const pi = b.inval + (w0 & 1023u);
-#else
-            const uint32_t *const pc0 = b.codes + w0;
-            const uint16_t *const pi0 = (hn >> 31) ? b.inval + w0 : b.inval; // clean read: any cached line will do, the mask is not looked at
-            // (said once more that these are wave-uniform: under register pressure hipcc has moved this address arithmetic
-            //  to the vector ALU and then handed the "s" operands below a VGPR pair -- a build error, seen once)
-            const uint32_t *const pc = reinterpret_cast<const uint32_t *>(uniform64((uint64_t)pc0));
-            const uint16_t *const pi = reinterpret_cast<const uint16_t *>(uniform64((uint64_t)pi0));
-#endif
-#if KID_WORDS_MASKED
-            // A read of the pair kernel (<= 128 k-mers, k <= 32, behind a shift of <= 15 bases) lies in its first 12 packed
-            // words, one of the duo kernel (<= 256 k-mers) in its first 20: only those lanes ask -- one or two 64-byte
-            // segments per request instead of four and two.  The other lanes keep their zeros.  (The mask is applied
-            // inside the statement: the compiler must not see a load in a branch of its own.)
-            const uint64_t word_lanes = PAIRK == 1 ? 0xFFFull : 0xFFFFFull;
+        // descriptors, 64 at a time: lane l holds the one of read number blk + l of this wave -- the low word
+        // of first_base, and its high word (< 2^16: a batch is smaller than 2^48 bytes) with n_kmers (<= 256
+        // in these kernels) above it.  Fixed layout: worked out on the spot, there are no descriptors in memory.
+        uint32_t blk = 0, dv_lo = 0, dv_hn = 0;
+        auto load_descs = [&](const uint32_t first, const uint32_t len) { // reads first .. first + len - 1 of the launch -> lanes 0 .. len - 1
+            KidReadDesc d;
+            d.first_base = 0; d.n_kmers = 0; d.pad = 0;
+            const uint32_t rr = first + lane;
+            const KidReadDesc *const dp = static_cast<const KidReadDesc *>(rare->desc);
+            if (lane < len) {
+                if (dp) d = dp[rr];
+                else { d.first_base = (rare->read0 + rr) * (unsigned long long)rare->fixed_len; d.n_kmers = rare->fixed_nk; }
+            }
+            dv_lo = (uint32_t)d.first_base;
+            dv_hn = ((uint32_t)(d.first_base >> 32) & 0xFFFFu) | ((d.n_kmers > 0 ? (uint32_t)d.n_kmers : 0u) << 16);
+            if (PAIRK == 1 && lane < len) RG[(blk + lane) & 127u] = rr;
+        };
+        auto issue_words = [&](const uint32_t idx, Raw &x) {
+            const uint32_t hn = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)idx); // [15:0] first_base >> 32, [30:16] n_kmers
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)idx);
+            const uint64_t w0 = (((uint64_t)(hn & 0xFFFFu) << 32) | lo) >> 4;
+            // (said once more that this is wave-uniform: under register pressure hipcc has moved such address arithmetic
+            //  to the vector ALU and then handed the "s" operand below a VGPR pair -- a build error, seen once)
+            const uint8_t *const p = reinterpret_cast<const uint8_t *>(uniform64((uint64_t)(b.bases + 16ull * w0)));
+            const uint64_t lanes = ask_lanes(lo & 15u, (hn >> 16) & 0x7FFFu);
             uint64_t save;
-            if (PAIRK == 1 && KID_ROW_WORDS) {
-                // row-wise: lane 16 r + j asks for word r + j (j <= 10: tile 1 of row 3 reaches word 10, the m-mers behind
-                // the last tile words 8..10 of row 0); the masks keep the lane = word order (only unclean reads look at them)
-                asm volatile("s_mov_b64 %2, exec\n\ts_mov_b64 exec, %5\n\tglobal_load_dword %0, %3, %4\n\ts_mov_b64 exec, %8\n\tglobal_load_ushort %1, %6, %7\n\ts_mov_b64 exec, %2"
-                             : "+v"(c), "+v"(iv), "=&s"(save) : "v"(lane4row), "s"(pc), "s"(0x07FF07FF07FF07FFull), "v"(lane4 >> 1), "s"(pi), "s"(word_lanes) : "memory");
-            } else
-            asm volatile("s_mov_b64 %2, exec\n\ts_mov_b64 exec, %5\n\tglobal_load_dword %0, %3, %4\n\tglobal_load_ushort %1, %6, %7\n\ts_mov_b64 exec, %2"
-                         : "+v"(c), "+v"(iv), "=&s"(save) : "v"(lane4), "s"(pc), "s"(word_lanes), "v"(lane4 >> 1), "s"(pi) : "memory");
-#else
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(c) : "v"(lane4), "s"(pc) : "memory");
-            asm volatile("global_load_ushort %0, %1, %2" : "=v"(iv) : "v"(lane4 >> 1), "s"(pi) : "memory");
-#endif
+            if constexpr (PAIRK == 1)
+                asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %4\n\tglobal_load_dword %0, %2, %3\n\ts_mov_b64 exec, %1"
+                             : "+v"(x), "=&s"(save) : "v"(lane_off), "s"(p), "s"(lanes) : "memory");
+            else
+                asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %4\n\tglobal_load_dwordx2 %0, %2, %3\n\ts_mov_b64 exec, %1"
+                             : "+v"(x), "=&s"(save) : "v"(lane_off), "s"(p), "s"(lanes) : "memory");
+        };
+        // ASCII -> packed words, in registers.  A lane packs its own 4 (8) bases (kid_codes4), shifts them to their place
+        // in the read's 16-base word, and the 4 (2) lanes of a word OR their parts together over DPP quad permutes:
+        // afterwards every lane of the group holds the whole word, which is where group_front's ds_bpermute looks for
+        // it.  Returns "no base of the read resets a window": decided on the scalar unit from the ballot of the lanes
+        // whose bytes hold something that is not ACGT -- the lanes that did not ask hold stale text, and the first and
+        // the last lane of a read also hold bytes in front of / behind it (the neighbouring read; the line ends of a
+        // FASTQ block), which must not count.  Only for a read that does have such a base are the 16-bit masks of its
+        // words put together (wi; else 0: nobody looks).
+        const uint32_t part_c = PAIRK == 1 ? 24u - 8u * (lane & 3u) : 16u - 16u * (lane & 1u); // where a lane's codes go in its word
+        auto pack_lanes = [&](const Raw x, const uint32_t sh, const uint32_t nk, uint32_t &wc, uint32_t &wi) -> bool {
+            uint32_t c, d0, d1 = 0;
+            if constexpr (PAIRK == 1) c = kid_codes4(x, db.u_is_t, d0);
+            else c = (kid_codes4(x.x, db.u_is_t, d0) << 8) | kid_codes4(x.y, db.u_is_t, d1);
+            c <<= part_c;
+            c |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xF, 0xF, false);   // quad_perm:[1,0,3,2]
+            if constexpr (PAIRK == 1) c |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x4E, 0xF, 0xF, false); // quad_perm:[2,3,0,1]
+            wc = c;
+            wi = 0;
+            const uint64_t bad = __ballot((d0 | d1) != 0) & ask_lanes(sh, nk);
+            if (bad == 0 || nk == 0) return true;
+            // (rare, wave-uniform from here on) bytes [sh, end) of the loaded text are the read's
+            const uint32_t end = sh + nk + (uint32_t)k - 1u, lf = sh / BPL, ll = (end - 1u) / BPL;
+            uint64_t inside = bad & ~((1ull << lf) | (1ull << ll));
+            if (inside == 0) { // only the two lanes at the read's ends: look at their bytes
+                auto lane_bytes = [&](const uint32_t l) -> uint64_t {
+                    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)d1, (int)l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)l);
+                };
+                const uint64_t all = BPL == 4u ? 0xFFFFFFFFull : ~0ull;
+                const uint64_t from = all << (8u * (sh % BPL)), upto = all >> (8u * (BPL - 1u - ((end - 1u) % BPL)));
+                inside = lf == ll ? (lane_bytes(lf) & from & upto) : ((lane_bytes(lf) & from) | (lane_bytes(ll) & upto));
+            }
+            if (inside == 0) return true;
+            uint32_t iv = PAIRK == 1 ? kid_inv4(d0) << (4u * (lane & 3u)) : (kid_inv4(d0) | (kid_inv4(d1) << 4)) << (8u * (lane & 1u));
+            iv |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)iv, 0xB1, 0xF, 0xF, false);
+            if constexpr (PAIRK == 1) iv |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)iv, 0x4E, 0xF, 0xF, false);
+            wi = iv;
+            return false;
         };
         auto issue_header = [&](const KidGroup<U> &g, const int u) -> kid_u4 {
             const uint4 *const p = db.table + (g.act[u] ? g.hlo[u] * KID_LINE_CELLS : 0u);
             kid_u4 v;
-#ifdef KID_HDR_NT // experiment: non-temporal header loads (the random-line ceiling is 54 instead of 48.5 G lines/s with them)
-            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(v) : "v"(p) : "memory");
-#else
             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
-#endif
             return v;
         };
-        uint32_t cA = 0, iA = 0, cB = 0, iB = 0;
+        Raw xA{}, xB{};
         if constexpr (PAIRK == 2) {
-            load_block();
-            issue_words(0u, cA, iA);
-            issue_words(1u, cB, iB);
+            load_descs(duo_first, cnt < 64u ? cnt : 64u);
+            issue_words(0u, xA);
+            issue_words(1u, xB);
             // ---- reads of two groups (129..256 k-mers: 2 x 250 bp): the pair is the two groups of ONE read.
-            // They share the read's packed words, their queue entries carry the same tag, and the read
-            // stays open in the resolver between them.  Two word sets alternate, each requested two trips
-            // ahead (a trip is one read here).
-            auto duo = [&](const uint32_t i, uint32_t &cC, uint32_t &iC) { // (cC, iC): the word set that holds read i
+            // They share the read's words, their queue entries carry the same tag, and the read stays open in the
+            // resolver between them.  Two text registers alternate, each requested two trips ahead (a trip is one
+            // read here).
+            auto duo = [&](const uint32_t i, Raw &xC) { // xC: the register that holds the text of read i
                 const uint32_t ia = i - blk;
                 const uint32_t hnC = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)ia);
                 const uint32_t nk = (hnC >> 16) & 0x7FFFu;
@@ -1466,21 +1285,25 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
                 const uint32_t nb = nk + (uint32_t)k - 1;
                 KidGroup<U> gA, gB;
                 uint32_t bad = 0;
-                if (ia + 2u > 63u) { blk = i + 1u; load_block(); } // (this read's descriptor is in scalars by now)
-                asm volatile("s_waitcnt vmcnt(2)" : "+v"(cC), "+v"(iC) : : "memory"); // behind: the words of the next read (other set)
-                const bool cl = !(hnC >> 31) || (__ballot(iC != 0) == 0);
+                if (ia + 2u > 63u) { // (this read's descriptor is in scalars by now)
+                    blk = i + 1u;
+                    load_descs(duo_first + blk, cnt - blk < 64u ? cnt - blk : 64u);
+                }
+                asm volatile("s_waitcnt vmcnt(1)" : "+v"(xC) : : "memory"); // behind: the text of the next read (other register)
+                uint32_t cC, iC;
+                const bool cl = pack_lanes(xC, sh, nk, cC, iC);
                 group_front(nullptr, sh, nb, nk, 0u, cl, gA, bad, false, cC, iC);
                 kid_u4 hA0 = issue_header(gA, 0), hA1 = issue_header(gA, 1);
                 group_front(nullptr, sh, nb, nk, (uint32_t)(U * 64), cl, gB, bad, false, cC, iC);
                 kid_u4 hB0 = issue_header(gB, 0), hB1 = issue_header(gB, 1);
-                issue_words(i + 2u - blk, cC, iC); // this set is used up: the read after the next, two trips ahead
+                issue_words(i + 2u - blk, xC); // this register is used up: the read after the next, two trips ahead
                 n_lookups += nk - bad;
-                asm volatile("s_waitcnt vmcnt(4)" : "+v"(hA0), "+v"(hA1) : : "memory"); // behind: the headers of B, the words just requested
+                asm volatile("s_waitcnt vmcnt(3)" : "+v"(hA0), "+v"(hA1) : : "memory"); // behind: the headers of B, the text just requested
                 gA.hd[0] = make_uint4(hA0.x, hA0.y, hA0.z, hA0.w);
                 gA.hd[1] = make_uint4(hA1.x, hA1.y, hA1.z, hA1.w);
                 bool had = back_deferred(gA, i);
                 if (qn >= KID_CQ_FLUSH) resolve_all(i, i & 63u); // the read stays open
-                asm volatile("s_waitcnt vmcnt(2)" : "+v"(hB0), "+v"(hB1) : : "memory"); // behind: the words just requested
+                asm volatile("s_waitcnt vmcnt(1)" : "+v"(hB0), "+v"(hB1) : : "memory"); // behind: the text just requested
                 gB.hd[0] = make_uint4(hB0.x, hB0.y, hB0.z, hB0.w);
                 gB.hd[1] = make_uint4(hB1.x, hB1.y, hB1.z, hB1.w);
                 had |= back_deferred(gB, i);
@@ -1492,220 +1315,46 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
                 }
             };
             for (uint32_t i = 0; i < cnt; i += 2) {
-                duo(i, cA, iA);
-                if (i + 1u < cnt) duo(i + 1u, cB, iB);
+                duo(i, xA);
+                if (i + 1u < cnt) duo(i + 1u, xB);
             }
             if (qn || cur_tag != 0xFFFFFFFFu) resolve_all(cnt - 1u, 0xFFFFFFFFu);
             if (cnt & 63u) flush_results(cnt & ~63u, cnt & 63u);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cA), "+v"(iA), "+v"(cB), "+v"(iB) : : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(xA), "+v"(xB) : : "memory");
         } else {
-        // Which reads a wave classifies is not fixed in advance.  The SIMD's issue arbitration prefers its older waves,
-        // so with equal shares the waves of a launch finish far apart (2 M reads: the mean wave was through after 1.0 ms,
-        // the last one after 1.5 ms, the launch ending at a falling occupancy).  Instead a wave draws BLOCKS of consecutive
-        // reads from a counter -- 16 reads at a time, fewer as its counter's pool runs dry -- one block ahead of the one
-        // it is working on: the fetch-and-add for the block after the next is in flight while a block is classified, and
-        // the descriptors of the next block are loaded during the block's last pair, like those of a wave's next 64 reads
-        // were before.  KID_DYN_SHARDS counters (64 bytes apart) share the reads of a launch evenly; the workgroups of all
-        // XCDs take turns on a counter (blockIdx >> 3).  KID_DYNAMIC = 0: the old strided shares, blocks of 64.
+        // ---- the pair kernel.  A wave takes blocks of 64 CONSECUTIVE reads: the text (9.6 KB at 150 bp) and the results
+        // (256 bytes) of a block are lines that no other wave -- no other L2 -- touches; its blocks are one contiguous
+        // share of the launch.  Shares shrink: the first half of the workgroups (dispatched first) take KID_TAPER units
+        // of reads per wave, the second half one.  Workgroups take 200-330 us for the same number of reads (the SIMDs
+        // serve their oldest waves first), and a launch ends when the slowest of its last workgroups does: with equal
+        // shares the chip idles through half the spread of a 250-us workgroup at the end of a 1-ms launch, with small
+        // last shares through a third of that (profiles/r02/ab_taper.txt, ab_block_cyclic.txt).
         const uint32_t n32 = (uint32_t)b.n;
-#ifdef KID_DYN_SHARD_HASH
-        const uint32_t sh = ((blockIdx.x * 0x9E3779B1u) >> 16) & (KID_DYN_SHARDS - 1u);
-#else
-        const uint32_t sh = (blockIdx.x >> 3) & (KID_DYN_SHARDS - 1u);
-#endif
-        const uint32_t sp = (((n32 + KID_DYN_SHARDS - 1u) / KID_DYN_SHARDS) + 1u) & ~1u; // reads per counter (even)
-        uint32_t cur_sh = sh;                                                             // the counter the wave draws from
-        uint32_t s0 = sh * sp < n32 ? sh * sp : n32;
-        uint32_t s1 = s0 + sp < n32 ? s0 + sp : n32;                                      // that counter's reads: [s0, s1)
-        const uint32_t shard_waves = ((gridDim.x + 8u * KID_DYN_SHARDS - 1u) / (8u * KID_DYN_SHARDS)) * 8u * wpb; // (upper bound)
-        uint32_t *ctr = rare->dyn + sh * 16u;
-        auto guided = [&](const uint32_t left) -> uint32_t { // smaller blocks towards the end of a pool, so that the waves finish together
-            uint32_t t = left / (2u * shard_waves);
-            t = t > KID_DYN_CHUNK ? KID_DYN_CHUNK : t;
-            return t < 2u ? 2u : (t & ~1u);
-        };
         uint32_t seq = 0;        // wave-local number of the pair's first read (even)
         uint32_t blen = 0;       // reads in the current block [blk, blk + blen)
         uint32_t nreal = 0;      // reads classified
-        uint32_t take = guided(s1 - s0); // reads the next fetch-and-add asks for
-        uint32_t gv = 0;         // lane 0: what the fetch-and-add in flight returned = first read of the block after the next
-        uint32_t sblk = 0;       // KID_DYNAMIC = 0: number of the wave's next strided block
-        // The next block: its first read, stride and length (0: none) -- dynamic: from the fetch-and-add that has been in
-        // flight since the block before (gv) -- then its descriptors; the fetch-and-add for the block after it goes out
-        // while those are on their way.  Descriptors: lane l holds the one of wave-local read blk + l.
+        uint32_t sblk = 0;       // number of the wave's next block
+        // the next block (length 0: none) and its descriptors: lane l holds the one of wave-local read blk + l
         auto switch_block = [&]() {
-            uint32_t first, stride, len;
-            bool again = false;
-            if (KID_DYNAMIC) {
-                uint32_t st = s0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)gv);
-                bool have = st < s1;
-                if (!have) {
-                    // This counter's reads are gone: on to the others'.  The waves of old workgroups are served first by
-                    // their SIMDs, so the pools do not run dry together; without this the waves of a fast pool would idle
-                    // through the rest of the launch.  A look before the fetch-and-add: at the end of a launch every
-                    // wave comes by here, and sixteen fetch-and-adds each would queue up on the counters.
-                    for (uint32_t kk = 1; kk < KID_DYN_SHARDS && !have; kk++) {
-                        const uint32_t s2 = (cur_sh + kk) & (KID_DYN_SHARDS - 1u);
-                        const uint32_t a0 = s2 * sp < n32 ? s2 * sp : n32, a1 = a0 + sp < n32 ? a0 + sp : n32;
-                        uint32_t *const c2 = rare->dyn + s2 * 16u;
-                        const uint32_t seen_v = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        if (seen_v >= a1 - a0) continue;
-                        const uint32_t t2 = guided(a1 - a0 - seen_v);
-                        uint32_t g2 = 0;
-                        if (lane == 0) g2 = atomicAdd(c2, t2);
-                        g2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g2);
-                        if (g2 < a1 - a0) { cur_sh = s2; s0 = a0; s1 = a1; ctr = c2; st = a0 + g2; take = t2; have = true; }
-                    }
-                }
-                len = 0;
-                if (have) {
-                    len = s1 - st < take ? s1 - st : take; // (take: what the fetch-and-add that returned st asked for)
-                    take = guided(s1 - st);
-                    again = true;
-                }
-                first = st;
-                stride = 1u;
-            } else {
-#if KID_BLOCK_CYCLIC
-                // blocks of 64 CONSECUTIVE reads, dealt out wave by wave: the descriptors (1 KiB), packed words (2.4 KB)
-                // and results (256 bytes) of a block are lines that no other wave -- no other L2 -- touches.  With
-                // strided shares (read i of wave w = w + i x waves) every such line was shared by up to eight waves on
-                // as many XCDs, each of which missed on it in its own L2
-#if KID_TAPER
-                // ... in shares that shrink: the first half of the workgroups (dispatched first) take KID_TAPER units of reads
-                // per wave, the second half one.  Workgroups take 200-330 us for the same number of reads, and a launch
-                // ends when the slowest of its last workgroups does: with equal shares the chip idles through half the
-                // spread of a 250-us workgroup at the end of a 1-ms launch, with small last shares through a third of that.
-                const uint32_t G = gridDim.x, half = G >> 1, wg = blockIdx.x;
-                const uint32_t units = wpb * (KID_TAPER * half + (G - half));    // shares of one unit per wave
-                const uint32_t unit = (((n32 + units - 1u) / units) + 1u) & ~1u; // reads per unit (even)
-                const uint32_t mine = wg < half ? KID_TAPER : 1u;
-                const uint64_t ufirst = (uint64_t)wpb * (wg < half ? KID_TAPER * wg : KID_TAPER * half + (wg - half)) + (uint64_t)wib * mine;
-                const uint64_t wave_first = ufirst * unit, off = (uint64_t)sblk * 64u, wave_cnt = (uint64_t)mine * unit;
-                sblk++;
-                const uint64_t f64 = wave_first + off;
-                first = f64 < n32 ? (uint32_t)f64 : n32;
-                stride = 1u;
-                len = off < wave_cnt ? (uint32_t)(wave_cnt - off < 64u ? wave_cnt - off : 64u) : 0u;
-                if (len > n32 - first) len = n32 - first;
-#else
-                const uint64_t f64 = ((uint64_t)gw32 + (uint64_t)sblk * nw32) * 64u;
-                sblk++;
-                first = f64 < n32 ? (uint32_t)f64 : n32;
-                stride = 1u;
-                len = n32 - first < 64u ? n32 - first : 64u;
-#endif
-#else
-                const uint32_t j0 = sblk * 64u;
-                sblk++;
-                first = gw32 + j0 * nw32;
-                stride = nw32;
-                len = j0 < cnt ? (cnt - j0 < 64u ? cnt - j0 : 64u) : 0u;
-#endif
-            }
-            KidReadDesc d;
-            d.first_base = 0; d.n_kmers = 0; d.pad = 0;
-            const uint32_t rr = first + lane * stride;
-            if (lane < len) d = static_cast<const KidReadDesc *>(rare->desc)[rr];
-            if (KID_DYNAMIC && again) { gv = 0; if (lane == 0) gv = atomicAdd(ctr, take); }
-            dv_lo = (uint32_t)d.first_base;
-            dv_hn = ((uint32_t)(d.first_base >> 32) & 0xFFFFu) | ((d.n_kmers > 0 ? (uint32_t)d.n_kmers : 0u) << 16) | ((d.pad & 1u) << 31);
-            if (lane < len) RG[(blk + lane) & 127u] = rr;
+            const uint32_t G = gridDim.x, half = G >> 1, wg = blockIdx.x;
+            const uint32_t units = wpb * (KID_TAPER * half + (G - half));    // shares of one unit per wave
+            const uint32_t unit = (((n32 + units - 1u) / units) + 1u) & ~1u; // reads per unit (even)
+            const uint32_t mine = wg < half ? KID_TAPER : 1u;
+            const uint64_t ufirst = (uint64_t)wpb * (wg < half ? KID_TAPER * wg : KID_TAPER * half + (wg - half)) + (uint64_t)wib * mine;
+            const uint64_t wave_first = ufirst * unit, off = (uint64_t)sblk * 64u, wave_cnt = (uint64_t)mine * unit;
+            sblk++;
+            const uint64_t f64 = wave_first + off;
+            const uint32_t first = f64 < n32 ? (uint32_t)f64 : n32;
+            uint32_t len = off < wave_cnt ? (uint32_t)(wave_cnt - off < 64u ? wave_cnt - off : 64u) : 0u;
+            if (len > n32 - first) len = n32 - first;
+            load_descs(first, len);
             blen = len;
         };
-        if (KID_DYNAMIC) {
-            if (lane == 0 && s0 < s1) gv = atomicAdd(ctr, take);
-        }
-#ifdef KID_ENDHIST
-        uint32_t eh_last = 0, eh_nblk = 1;
-#endif
         switch_block();
         bool more = blen != 0;
-#if KID_SKEW
-        // Skewed schedule.  The header test of a pair's second read (B) waits for the NEXT trip, between the front halves of
-        // the next pair: front A, [test of the previous B], front B, test A.  In the straight order (front A, front B,
-        // test A, test B) the headers of B were asked for one short test before they were needed, and every trip of every
-        // wave sat out most of a round trip to HBM there; now both header requests of a trip are half a trip old when
-        // their wait comes.  Register pressure is that of the straight order's front B (one read's keys, fingerprints and
-        // headers live during the other read's front half).  Queue entries stay in read order: A_i, B_i, A_i+1.
-        KidGroup<U> gB;
-        gB.act[0] = false; gB.act[1] = false; gB.hlo[0] = 0; gB.hlo[1] = 0; gB.fpp = 0; gB.key[0] = 0; gB.key[1] = 0;
-        gB.hd[0] = make_uint4(0, 0, 0, 0); gB.hd[1] = make_uint4(0, 0, 0, 0);
-        kid_u4 hB0 = {0, 0, 0, 0}, hB1 = {0, 0, 0, 0};
-        bool pendB = false; // the previous pair's B is a real read whose headers have not been looked at
         if (more) {
-            // two stand-ins for "the headers of the previous B" (cell 0, nobody looks at them): the explicit counts of
-            // the first trip are then those of every trip
-            issue_words(0u, cA, iA);
-            hB0 = issue_header(gB, 0); hB1 = issue_header(gB, 1);
-            issue_words(1u, cB, iB);
-        }
-        auto test_B = [&](const uint32_t iB_) {
-            gB.hd[0] = make_uint4(hB0.x, hB0.y, hB0.z, hB0.w);
-            gB.hd[1] = make_uint4(hB1.x, hB1.y, hB1.z, hB1.w);
-            if (!back_deferred(gB, iB_)) commit_zero(iB_);
-            else if (qn >= KID_CQ_FLUSH) resolve_all(iB_, 0xFFFFFFFFu);
-        };
-        while (more) {
-            const uint32_t i = seq;
-            const uint32_t ia = i - blk;
-            const uint32_t hnA = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)ia), hnB = (uint32_t)__builtin_amdgcn_readlane((int)dv_hn, (int)(ia + 1u));
-            const uint32_t nkA = (hnA >> 16) & 0x7FFFu, nkB = (hnB >> 16) & 0x7FFFu;
-            const uint32_t shA = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)ia) & 15u;
-            const uint32_t shB = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)(ia + 1u)) & 15u;
-            const bool realB = ia + 1u < blen; // (a block with an odd number of reads -- the last of a pool: B is a phantom of zero k-mers)
-            KidGroup<U> gA;
-            uint32_t badA = 0, badB = 0;
-            // the block's last pair: the next block's descriptors (this pair's are in scalars by now)
-            if (ia + 2u >= blen) {
-                blk = i + 2u;
-                switch_block(); // (no block: all-zero descriptors, the word requests below fetch what nobody needs)
-                more = blen != 0;
-            }
-
-            asm volatile("s_waitcnt vmcnt(4)" : "+v"(cA), "+v"(iA) : : "memory"); // behind: the headers of the previous B, the words of B
-            const bool clA = !(hnA >> 31) || (__ballot(iA != 0) == 0); // no base of the read resets a window
-            group_front(nullptr, shA, nkA + (uint32_t)k - 1, nkA, 0u, clA, gA, badA, false, cA, iA);
-            kid_u4 hA0 = issue_header(gA, 0), hA1 = issue_header(gA, 1);
-            issue_words(i + 2u - blk, cA, iA); // the packed words of the next pair, a whole trip ahead (they come from HBM)
-            n_lookups += nkA - badA;
-
-            asm volatile("s_waitcnt vmcnt(6)" : "+v"(hB0), "+v"(hB1) : : "memory"); // behind: the words of B, headers and next words of A
-            if (pendB) test_B(i - 1u);
-            if ((i & 63u) == 0u && i != 0u) { // tags and result slots are wave-local read numbers mod 64
-                if (qn) resolve_all(i - 1u, 0xFFFFFFFFu);
-                flush_results(i - 64u, 64u);
-            }
-
-            asm volatile("s_waitcnt vmcnt(4)" : "+v"(cB), "+v"(iB) : : "memory"); // behind: headers and next words of A
-            const bool clB = !(hnB >> 31) || (__ballot(iB != 0) == 0);
-            group_front(nullptr, shB, nkB + (uint32_t)k - 1, nkB, 0u, clB, gB, badB, false, cB, iB);
-            hB0 = issue_header(gB, 0); hB1 = issue_header(gB, 1);
-            issue_words(i + 3u - blk, cB, iB);
-            pendB = realB;
-            nreal += realB ? 2u : 1u;
-            if (realB) n_lookups += nkB - badB;
-
-            asm volatile("s_waitcnt vmcnt(6)" : "+v"(hA0), "+v"(hA1) : : "memory"); // behind: next words of A, headers and next words of B
-            gA.hd[0] = make_uint4(hA0.x, hA0.y, hA0.z, hA0.w);
-            gA.hd[1] = make_uint4(hA1.x, hA1.y, hA1.z, hA1.w);
-            if (!back_deferred(gA, i)) commit_zero(i);
-            else if (qn >= KID_CQ_FLUSH) resolve_all(i, 0xFFFFFFFFu);
-            seq = i + 2u;
-        }
-        // (the requests behind the last pair fetched words nobody needs; a fetch-and-add may still be out)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cA), "+v"(iA), "+v"(cB), "+v"(iB), "+v"(gv), "+v"(hB0), "+v"(hB1) : : "memory");
-        if (pendB) test_B(seq - 1u);
-        // a block of odd length ends the wave's work: seq counts its phantom, the flush below must not
-        if (nreal & 1u) seq -= 1u;
-        reads_done = seq;
-        if (qn) resolve_all(seq - 1u, 0xFFFFFFFFu);
-        if (seq & 63u) flush_results(seq & ~63u, seq & 63u);
-        else if (seq) flush_results(seq - 64u, 64u); // (a full last block: its in-loop flush would have come with the next trip)
-#else
-        if (more) {
-            issue_words(0u, cA, iA);
-            issue_words(1u, cB, iB);
+            issue_words(0u, xA);
+            issue_words(1u, xB);
         }
         while (more) {
             const uint32_t i = seq;
@@ -1714,48 +1363,40 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             const uint32_t nkA = (hnA >> 16) & 0x7FFFu, nkB = (hnB >> 16) & 0x7FFFu;
             const uint32_t shA = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)ia) & 15u;
             const uint32_t shB = (uint32_t)__builtin_amdgcn_readlane((int)dv_lo, (int)(ia + 1u)) & 15u;
-            const bool realB = ia + 1u < blen; // (a block with an odd number of reads -- the last of a pool: B is a phantom of zero k-mers)
+            const bool realB = ia + 1u < blen; // (a block with an odd number of reads -- the last of a share: B is a phantom of zero k-mers)
             KidGroup<U> gA, gB;
             uint32_t badA = 0, badB = 0;
             // the block's last pair: the next block's descriptors (this pair's are in scalars by now)
             if (ia + 2u >= blen) {
                 blk = i + 2u;
-                switch_block(); // (no block: all-zero descriptors, the word requests below fetch what nobody needs)
+                switch_block(); // (no block: all-zero descriptors, the requests below fetch four bytes nobody needs)
                 more = blen != 0;
-#ifdef KID_ENDHIST
-                if (more) { eh_last = (uint32_t)(__builtin_amdgcn_s_memrealtime() - rare->stats[30]); eh_nblk++; }
-#endif
             }
 
-            // The packed words of the next pair are requested as soon as this pair's are used up, a whole
-            // trip ahead: they come from HBM (the packed image of a batch is larger than the L2).
-            asm volatile("s_waitcnt vmcnt(2)" : "+v"(cA), "+v"(iA) : : "memory"); // behind: the words of B
-            KID_TICK(0);
-            const bool clA = !(hnA >> 31) || (__ballot(iA != 0) == 0); // no base of the read resets a window
+            // The text of the next pair is requested as soon as this pair's is used up, a whole trip ahead:
+            // it comes from HBM (a batch is larger than the L2).
+            asm volatile("s_waitcnt vmcnt(1)" : "+v"(xA) : : "memory"); // behind: the text of B
+            uint32_t cA, iA;
+            const bool clA = pack_lanes(xA, shA, nkA, cA, iA); // no base of the read resets a window
             group_front(nullptr, shA, nkA + (uint32_t)k - 1, nkA, 0u, clA, gA, badA, false, cA, iA);
             kid_u4 hA0 = issue_header(gA, 0), hA1 = issue_header(gA, 1);
-            issue_words(i + 2u - blk, cA, iA);
-            KID_TICK(1);
+            issue_words(i + 2u - blk, xA);
 
-            asm volatile("s_waitcnt vmcnt(4)" : "+v"(cB), "+v"(iB) : : "memory"); // behind: headers of A, next words of A
-            KID_TICK(2);
-            const bool clB = !(hnB >> 31) || (__ballot(iB != 0) == 0);
+            asm volatile("s_waitcnt vmcnt(3)" : "+v"(xB) : : "memory"); // behind: headers of A, next text of A
+            uint32_t cB, iB;
+            const bool clB = pack_lanes(xB, shB, nkB, cB, iB);
             group_front(nullptr, shB, nkB + (uint32_t)k - 1, nkB, 0u, clB, gB, badB, false, cB, iB);
             kid_u4 hB0 = issue_header(gB, 0), hB1 = issue_header(gB, 1);
-            issue_words(i + 3u - blk, cB, iB);
-            KID_TICK(3);
+            issue_words(i + 3u - blk, xB);
 
-            asm volatile("s_waitcnt vmcnt(6)" : "+v"(hA0), "+v"(hA1) : : "memory"); // behind: next words of A, headers and next words of B
-            KID_TICK(4);
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(hA0), "+v"(hA1) : : "memory"); // behind: next text of A, headers and next text of B
             gA.hd[0] = make_uint4(hA0.x, hA0.y, hA0.z, hA0.w);
             gA.hd[1] = make_uint4(hA1.x, hA1.y, hA1.z, hA1.w);
             n_lookups += nkA - badA;
             if (!back_deferred(gA, i)) commit_zero(i);
             else if (qn >= KID_CQ_FLUSH) resolve_all(i, 0xFFFFFFFFu);
-            KID_TICK(5);
 
-            asm volatile("s_waitcnt vmcnt(2)" : "+v"(hB0), "+v"(hB1) : : "memory"); // behind: the next words of B
-            KID_TICK(6);
+            asm volatile("s_waitcnt vmcnt(1)" : "+v"(hB0), "+v"(hB1) : : "memory"); // behind: the next text of B
             gB.hd[0] = make_uint4(hB0.x, hB0.y, hB0.z, hB0.w);
             gB.hd[1] = make_uint4(hB1.x, hB1.y, hB1.z, hB1.w);
             nreal += realB ? 2u : 1u;
@@ -1764,60 +1405,21 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
                 if (!back_deferred(gB, i + 1u)) commit_zero(i + 1u);
                 else if (qn >= KID_CQ_FLUSH) resolve_all(i + 1u, 0xFFFFFFFFu);
             }
-            KID_TICK(7);
             seq = i + 2u;
             if ((seq & 63u) == 0u) { // tags and result slots are wave-local read numbers mod 64
                 if (qn) resolve_all(i + 1u, 0xFFFFFFFFu);
                 flush_results(seq - 64u, 64u);
-#ifdef KID_WAVEPROF
-                {
-                    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-                    if (lane == 0 && wp_q < 4u) atomicAdd(&rare->stats[8 + wp_q], t - wp_prev); // time for reads 64q .. 64q+63
-                    wp_prev = t;
-                    wp_q++;
-                }
-#endif
             }
         }
-        // (the two requests behind the last pair fetched words nobody needs; a fetch-and-add may still be out)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cA), "+v"(iA), "+v"(cB), "+v"(iB), "+v"(gv) : : "memory");
+        // (the two requests behind the last pair fetched text nobody needs)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xA), "+v"(xB) : : "memory");
         // a block of odd length ends the wave's work: seq counts its phantom, the flush below must not
         if (nreal & 1u) seq -= 1u;
         reads_done = seq;
         if (qn) resolve_all(seq - 1u, 0xFFFFFFFFu);
         if (seq & 63u) flush_results(seq & ~63u, seq & 63u);
-#endif
-#ifdef KID_ENDHIST // development aid: when do the waves of a launch run out of reads?  24 bins of 64 us + a record per wave
-        if (lane == 0) {
-            const unsigned long long rel = __builtin_amdgcn_s_memrealtime() - rare->stats[30];
-            const unsigned long long bin = rel / 6400ull;
-            atomicAdd(&rare->stats[8 + (bin < 23ull ? bin : 23ull)], 1ull);
-            if (gw < 16384u) { // (the record area holds 16384 waves: kid_api.hip; a grid of 16 workgroups per CU has 32768)
-                uint32_t *rec = rare->dyn + KID_DYN_SHARDS * 16u + 4u * (uint32_t)gw;
-                rec[0] = seq;                 // reads classified
-                rec[1] = (uint32_t)rel;       // end of its loop, 10 ns ticks from the launch's first workgroup start
-                rec[2] = eh_last;             // start of its last block
-                rec[3] = eh_nblk;             // blocks drawn
-            }
-        }
-#endif
-#ifdef KID_WAVEPROF
-        if (lane == 0) {
-            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-            atomicAdd(&rare->stats[12], t - wp_prev);                      // the reads behind the last full block of 64
-            atomicAdd(&rare->stats[13], t - wp_t0);                        // sum of wave lifetimes (loop only)
-            atomicMin(&rare->stats[14], t - rare->stats[30]);              // first wave through, relative to the kernel's first start
-            atomicMax(&rare->stats[15], t - rare->stats[30]);              // last wave through
-            atomicAdd(&rare->stats[16], wp_t0 - rare->stats[30]);          // sum of wave start delays
-            atomicMax(&rare->stats[17], wp_t0 - rare->stats[30]);          // last wave to start
-            // histogram of end times, 16 bins of 10 us from 0.9 ms
-            const unsigned long long rel = t - rare->stats[30];
-            atomicAdd(&rare->stats[18], (unsigned long long)(rel * rel / 100ull)); // sum of squares (in 100 ns^2 units)
-        }
-#endif
         }
     }
-#endif
     if constexpr (PAIRK == 0) {
         // Software pipeline, unrolled by two with two named register sets (A, B) so that nothing is
         // copied between stages: the descriptor of a read is requested two reads ahead (scalar loads)
@@ -1827,7 +1429,6 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
         // the wave's reads: rd_first + i rd_stride, i < gen_cnt -- a strided share of the batch, or (KID_TAPER, minimizer-
         // localised table) one contiguous range in the pair kernel's shrinking shares
         gen_cnt = gw32 < n32 ? (n32 - gw32 + nw32 - 1u) / nw32 : 0u;
-#if KID_TAPER
         if (MINLOC) {
             const uint32_t G = gridDim.x, half = G >> 1, wg = blockIdx.x;
             const uint32_t units = wpb * (KID_TAPER * half + (G - half));
@@ -1840,20 +1441,19 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             gen_cnt = n32 - rd_first < mine * unit ? n32 - rd_first : mine * unit;
             reads_done = gen_cnt;
         }
-#endif
         const uint32_t gf = rd_first, gs = rd_stride, gc = gen_cnt;
         KidReadDesc dA, dB;
-        uint32_t cA, iA, cB, iB;
+        kid_u4 xA, xB;
         fetch_desc(gc > 0u ? gf : n32, dA);
         fetch_desc(gc > 1u ? gf + gs : n32, dB);
-        fetch_words(dA, cA, iA);
+        fetch_words(dA, xA);
         for (uint32_t i = 0; i < gc; i += 2) { // i: number of the read within this wave
             const uint32_t r = gf + i * gs;
-            short_read(r, i, uniform64(dA.first_base), __builtin_amdgcn_readfirstlane(dA.n_kmers), cA, iA,
-                       [&]() { fetch_words(dB, cB, iB); fetch_desc(i + 2u < gc ? r + 2u * gs : n32, dA); });
+            short_read(r, i, uniform64(dA.first_base), __builtin_amdgcn_readfirstlane(dA.n_kmers), xA,
+                       [&]() { fetch_words(dB, xB); fetch_desc(i + 2u < gc ? r + 2u * gs : n32, dA); });
             if (i + 1u >= gc) break;
-            short_read(r + gs, i + 1u, uniform64(dB.first_base), __builtin_amdgcn_readfirstlane(dB.n_kmers), cB, iB,
-                       [&]() { fetch_words(dA, cA, iA); fetch_desc(i + 3u < gc ? r + 3u * gs : n32, dB); });
+            short_read(r + gs, i + 1u, uniform64(dB.first_base), __builtin_amdgcn_readfirstlane(dB.n_kmers), xB,
+                       [&]() { fetch_words(dA, xA); fetch_desc(i + 3u < gc ? r + 3u * gs : n32, dB); });
             if (MINLOC && ((i + 2u) & 63u) == 0u) { // tags and result slots are read numbers mod 64
                 if (qn || cur_tag != 0xFFFFFFFFu) resolve_all(i + 1u, 0xFFFFFFFFu);
                 flush_results(i + 2u - 64u, 64u);
@@ -1870,12 +1470,13 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
         rb_direct = true; // the other reads' results are stored already: these go out one by one
         for (uint32_t i = 0; i < gen_cnt; i++) {
             const uint64_t r = (uint64_t)rd_first + (uint64_t)i * rd_stride;
-            const KidReadDesc d = descs[r];
+            KidReadDesc d;
+            fetch_desc((uint32_t)r, d);
             const int64_t nk = (int64_t)__builtin_amdgcn_readfirstlane(d.n_kmers);
             if (nk <= KID_SEG_KMERS) continue;
-            uint32_t c0, i0;
-            fetch_words(d, c0, i0);
-            process_read(r, i, uniform64(d.first_base), nk, c0, i0, []() {});
+            kid_u4 x0;
+            fetch_words(d, x0);
+            process_read(r, i, uniform64(d.first_base), nk, x0, []() {});
             if (MINLOC && (qn || cur_tag != 0xFFFFFFFFu)) resolve_all(i, 0xFFFFFFFFu);
         }
     }
@@ -1888,11 +1489,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
 
     // ---- flush (with the minimizer-localised table the histogram packs two 16-bit counters per word:
     // the host keeps a workgroup below 65536 reads per launch)
-#ifdef KID_ABLATE_NOFLUSH // timing experiment only (gcount stays empty): what do the histogram's global atomics cost?
-    if (false) {
-#else
     if (HIST) {
-#endif
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < hist_words; i += blockDim.x) {
             const uint32_t v = hist[i];
@@ -1902,13 +1499,6 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
             } else if (v) atomicAdd(&rare->gcount[i], (unsigned long long)v);
         }
     }
-#ifdef KID_PROFILE
-    KID_TICK(8);
-    if (lane == 0) for (int i = 0; i < 10; i++) atomicAdd(&rare->stats[8 + i], prof[i]);
-#endif
-#ifdef KID_ABLATE
-    if (sink == 0x12345678u) atomicAdd(&rare->stats[7], 1ull);
-#endif
     if (lane == 0) {
         const unsigned long long tl = *WL, n_reads = reads_done;
         const uint32_t n_hits = WC[2];
@@ -1923,7 +1513,23 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) KID_CLASSIFY_ATTR void kid_c
         const unsigned long long v = WGS[threadIdx.x];
         if (v) atomicAdd(&rare->stats[threadIdx.x], v);
     }
-    if (threadIdx.x == 0) atomicMax(&s.stats[31], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (threadIdx.x == 0) {
+        // The launch's last workgroup banks the interval ([6] += ticks, [7] += 1) and re-arms the stamps for the next
+        // launch.  Everything here is an atomic performed in memory, one after the other (each returns before the next is
+        // issued): no fence -- a release / acquire fence at device scope writes back and invalidates the L2 of the
+        // wave's XCD (buffer_wbl2 / buffer_inv sc1), and 4096 of those per launch cost 0.2 ms of 1.1
+        // (profiles/r03/bench_fence_in_epilogue.json).
+        unsigned long long prev = atomicMax(&s.stats[31], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        asm volatile("" : "+v"(prev)); // (the stamp is in memory before this workgroup counts itself out)
+        unsigned long long done = atomicAdd(&s.stats[29], 1ull);
+        if (done + 1ull == (unsigned long long)gridDim.x) {
+            const unsigned long long a = atomicAdd(&s.stats[30], 0ull), z = atomicAdd(&s.stats[31], 0ull);
+            if (z > a) { atomicAdd(&s.stats[6], z - a); atomicAdd(&s.stats[7], 1ull); }
+            unsigned long long t0 = atomicExch(&s.stats[30], ~0ull), t1 = atomicExch(&s.stats[31], 0ull);
+            asm volatile("" : "+v"(t0), "+v"(t1));
+            atomicExch(&s.stats[29], 0ull);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ unit probes (parity tests)
@@ -1958,30 +1564,91 @@ __global__ void kid_msca_kernel(const KidDevDb db, const int32_t *x, const int32
     }
 }
 
-// process_qual, newkmer_10nx.cpp:714-760: one read per thread (sequential scan by nature)
+// process_qual, newkmer_10nx.cpp:714-760: the quality string of one read (len = length of its SEQUENCE, :716) ->
+// [start, stop].  A sequential scan by nature: one read per thread.
+__device__ __forceinline__ void kid_process_qual(const signed char *q, const int len, int &start, int &stop)
+{
+    start = 0;
+    stop = len - 1;
+    if (len <= 0) return;
+    while (q[start] < 49 && start < stop) start++;
+    while (q[stop] < 49 && stop > start) stop--;
+    if (start < stop - 4) {
+        int w = 0;
+        for (int i = 0; i < 4; i++) w += q[start + i] - 32;
+        while (w < 68 && start < stop - 4) { w += q[start + 4] - q[start]; start++; }
+    }
+    if (start < stop - 4) {
+        int w = 0;
+        for (int i = 0; i < 4; i++) w += q[stop - i] - 32;
+        while (w < 68 && start < stop - 4) { w += q[stop - 4] - q[stop]; stop--; }
+    }
+}
+
 __global__ void kid_trim_kernel(const uint8_t *quals, const uint64_t *offsets, uint64_t n, int k,
                                 int32_t *start_out, int32_t *stop_out, uint8_t *keep)
 {
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
-        const signed char *q = reinterpret_cast<const signed char *>(quals + offsets[r]);
         const int len = (int)(offsets[r + 1] - offsets[r]);
-        int start = 0, stop = len - 1;
-        if (len <= 0) { start_out[r] = 0; stop_out[r] = -1; keep[r] = 0; continue; }
-        while (q[start] < 49 && start < stop) start++;
-        while (q[stop] < 49 && stop > start) stop--;
-        if (start < stop - 4) {
-            int w = 0;
-            for (int i = 0; i < 4; i++) w += q[start + i] - 32;
-            while (w < 68 && start < stop - 4) { w += q[start + 4] - q[start]; start++; }
-        }
-        if (start < stop - 4) {
-            int w = 0;
-            for (int i = 0; i < 4; i++) w += q[stop - i] - 32;
-            while (w < 68 && start < stop - 4) { w += q[stop - 4] - q[stop]; stop--; }
-        }
+        int start, stop;
+        kid_process_qual(reinterpret_cast<const signed char *>(quals + offsets[r]), len, start, stop);
         start_out[r] = start;
         stop_out[r] = stop;
-        keep[r] = (stop - start >= k) ? 1 : 0;
+        keep[r] = (len > 0 && stop - start >= k) ? 1 : 0;
+    }
+}
+
+// A block of FASTQ text whose lines the host has found (kid_classify_fastq_async): process_qual + the ">= k" test
+// of :757 + the read descriptor, per record.  A record process_qual drops is not handed to process_read in the
+// reference, i.e. it is counted nowhere: the classify kernels see it as a read without k-mers (gcount[0]++), which
+// this kernel takes back (stats[5] counts them).  stats[8]: records whose quality line is shorter than the sequence
+// (qual.at() throws, :727).
+struct KidFastqRec {
+    uint32_t seq_off, seq_len, qual_off, qual_len; // byte offsets into the block's text
+};
+__global__ void kid_prepare_fastq_kernel(const uint8_t *text, const KidFastqRec *recs, uint64_t n, int k, KidReadDesc *desc,
+                                         int32_t *start_out, int32_t *stop_out, uint32_t *out_final, unsigned long long *stats,
+                                         unsigned long long *gcount, KidRareArgs *rare, uint32_t seq, int rebase)
+{
+    if (rebase && blockIdx.x == 0) kid_rebase(rare, desc, out_final, 0ull, 0u, 0);
+    uint32_t mx = 0, dropped = 0, bad = 0;
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+        const KidFastqRec rc = recs[r];
+        int start = 0, stop = -1;
+        if (rc.qual_len < rc.seq_len) bad++;
+        else kid_process_qual(reinterpret_cast<const signed char *>(text + rc.qual_off), (int)rc.seq_len, start, stop);
+        const bool keep = rc.seq_len > 0 && rc.qual_len >= rc.seq_len && stop - start >= k;
+        KidReadDesc d;
+        d.first_base = (uint64_t)rc.seq_off + (uint64_t)(start > 0 ? start : 0);
+        d.n_kmers = keep ? stop - start + 1 - (k - 1) : 0;
+        d.pad = 0;
+        desc[r] = d;
+        start_out[r] = start;
+        stop_out[r] = stop;
+        if (!keep) dropped++;
+        if (d.n_kmers > 0 && (uint32_t)d.n_kmers > mx) mx = (uint32_t)d.n_kmers;
+    }
+    __shared__ uint32_t s_mx, s_dropped, s_bad;
+    if (threadIdx.x == 0) { s_mx = 0; s_dropped = 0; s_bad = 0; }
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t y = (uint32_t)__shfl_xor((int)mx, o);
+        mx = y > mx ? y : mx;
+        dropped += (uint32_t)__shfl_xor((int)dropped, o);
+        bad += (uint32_t)__shfl_xor((int)bad, o);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (mx) atomicMax(&s_mx, mx);
+        if (dropped) atomicAdd(&s_dropped, dropped);
+        if (bad) atomicAdd(&s_bad, bad);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long v = ((unsigned long long)seq << 32) | s_mx;
+        if (v > *reinterpret_cast<volatile unsigned long long *>(&rare->batch_max)) atomicMax(&rare->batch_max, v);
+        if (s_dropped) { atomicAdd(&gcount[0], 0ull - (unsigned long long)s_dropped); atomicAdd(&stats[5], (unsigned long long)s_dropped); }
+        if (s_bad) atomicAdd(&stats[8], (unsigned long long)s_bad);
     }
 }
 

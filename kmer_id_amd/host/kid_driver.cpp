@@ -2,6 +2,7 @@
 
 #include <stdlib.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <iostream>
@@ -13,21 +14,40 @@ namespace kidhost {
 void die_kid(int rc)
 {
     std::cerr << "kmer_id_amd: " << kid_strerror(rc) << ": " << kid_last_error() << "\n";
-    exit(rc == KID_ERR_TABLE_FULL ? 1 : 3);
+    // (a quality line shorter than its sequence, found by the GPU's process_qual: the reference dies in std::string::at,
+    //  abort -> 134; "out of memory in table" is exit 1, newkmer_10nx.cpp:256-260)
+    exit(rc == KID_ERR_TABLE_FULL ? 1 : rc == KID_ERR_FORMAT ? 134 : 3);
+}
+
+static double seconds_since(const std::chrono::steady_clock::time_point &t0)
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
 void load_database(const std::string &tree_path, const std::string &probes_path, const std::string &cache_path, int k, int ntar,
-                   std::vector<int32_t> &parent, ProbeSet &ps, bool *from_cache)
+                   std::vector<int32_t> &parent, ProbeSet &ps, bool *from_cache, int threads, StartupTiming *timing,
+                   std::thread *cache_writer)
 {
     if (from_cache) *from_cache = false;
+    const auto t0 = std::chrono::steady_clock::now();
     if (!cache_path.empty() && load_db_cache(cache_path, tree_path, probes_path, k, ntar, parent, ps)) {
         if (from_cache) *from_cache = true;
+        if (timing) timing->cache_read_s = seconds_since(t0);
         return;
     }
     parent = load_tree(tree_path, ntar);
-    ps = load_probes_gz(probes_path, k);
-    if (!cache_path.empty() && !save_db_cache(cache_path, tree_path, probes_path, k, parent, ps))
-        std::cerr << "kmer_id_amd: could not write the database cache " << cache_path << "\n";
+    ps = load_probes_gz(probes_path, k, threads, timing);
+    if (cache_path.empty()) return;
+    // the cache is written beside the upload and the table build when the caller can wait for it later (it must: `ps`
+    // and `parent` are read until the writer is joined)
+    auto write = [cache_path, tree_path, probes_path, k, &parent, &ps, timing]() {
+        const auto t1 = std::chrono::steady_clock::now();
+        if (!save_db_cache(cache_path, tree_path, probes_path, k, parent, ps))
+            std::cerr << "kmer_id_amd: could not write the database cache " << cache_path << "\n";
+        if (timing) timing->cache_write_s = seconds_since(t1);
+    };
+    if (cache_writer) *cache_writer = std::thread(write);
+    else write();
 }
 
 Engine::~Engine()
@@ -181,9 +201,10 @@ std::unique_ptr<ReadBatch> Prefetcher::next(size_t index)
 
 long long run_file(Engine &e, Prefetcher &pf, size_t index, ReadSaver &saver)
 {
-    // Two batches in flight (kid_classify_batch_async): while the GPU classifies batch b, batch b + 1 is uploaded and
-    // the results of batch b - 1 go through the read saver -- in file order, which is what decides the "first 12
-    // reads of a target" (newkmer_10nx.cpp:608-612).
+    // Two batches in flight per device: while the GPU classifies batch b, batch b + 1 is uploaded and the results of
+    // batch b - 1 go through the read saver -- in file order, which is what decides the "first 12 reads of a target"
+    // (newkmer_10nx.cpp:608-612).  FASTQ files arrive as text blocks with a line index (FastqStream): those are trimmed
+    // and classified on the GPU (kid_classify_fastq_async); everything else as reads with their range.
     struct InFlight {
         std::unique_ptr<ReadBatch> batch;
         std::vector<uint32_t> final_targ;
@@ -197,21 +218,37 @@ long long run_file(Engine &e, Prefetcher &pf, size_t index, ReadSaver &saver)
         InFlight &f = q.front();
         int rc = kid_classify_wait(f.sample, f.ticket);
         if (rc != KID_OK) die_kid(rc);
-        saver.add_batch(*f.batch, f.final_targ);
+        n += saver.add_batch(*f.batch, f.final_targ, e.k);
         q.pop_front();
     };
-    while (std::unique_ptr<ReadBatch> b = pf.next(index)) {
-        q.emplace_back();
-        InFlight &f = q.back();
-        f.batch = std::move(b);
-        f.final_targ.resize(f.batch->size());
-        f.sample = e.samples[e.next_sample]; // batches are dealt round-robin over the devices
-        e.next_sample = (e.next_sample + 1) % e.samples.size();
-        int rc = kid_classify_batch_async(f.sample, f.batch->bases.data(), f.batch->offsets.data(), f.batch->start.data(),
-                                          f.batch->stop.data(), f.batch->size(), f.final_targ.data(), &f.ticket);
-        if (rc != KID_OK) die_kid(rc);
-        n += (long long)f.batch->size();
-        while (q.size() > max_in_flight) retire();
+    try {
+        while (std::unique_ptr<ReadBatch> b = pf.next(index)) {
+            q.emplace_back();
+            InFlight &f = q.back();
+            f.batch = std::move(b);
+            const size_t nr = f.batch->size();
+            f.final_targ.resize(nr);
+            f.sample = e.samples[e.next_sample]; // batches are dealt round-robin over the devices
+            e.next_sample = (e.next_sample + 1) % e.samples.size();
+            int rc;
+            if (f.batch->fq) {
+                FastqBlock &fb = *f.batch->fq;
+                f.batch->start.resize(nr);
+                f.batch->stop.resize(nr);
+                rc = kid_classify_fastq_async(f.sample, (const uint8_t *)fb.text.data(), fb.used, fb.recs.data(), nr, f.final_targ.data(),
+                                              f.batch->start.data(), f.batch->stop.data(), &f.ticket);
+            } else {
+                rc = kid_classify_batch_async(f.sample, f.batch->bases.data(), f.batch->offsets.data(), f.batch->start.data(),
+                                              f.batch->stop.data(), nr, f.final_targ.data(), &f.ticket);
+            }
+            if (rc != KID_OK) die_kid(rc);
+            while (q.size() > max_in_flight) retire();
+        }
+    } catch (const Fatal &) {
+        // the file failed behind the batches handed out so far: those are the library's until waited for, and the
+        // reference had processed them before it met the failure
+        while (!q.empty()) retire();
+        throw;
     }
     while (!q.empty()) retire();
     return n;
@@ -226,16 +263,29 @@ void dry_dump_db(FILE *f, const std::vector<int32_t> &parent, const ProbeSet &ps
     for (size_t i = 0; i < ps.keys.size(); i++) fprintf(f, "%llu %u\n", (unsigned long long)ps.keys[i], ps.targets[i]);
 }
 
-void dry_dump_source(FILE *f, const std::string &label, ReadSource &src, size_t batch_reads)
+void dry_dump_source(FILE *f, const std::string &label, ReadSource &src, size_t batch_reads, int k)
 {
     ReadBatch b;
     fprintf(f, "FILE %s\n", label.c_str());
-    while (src.fill(b, batch_reads, (size_t)-1))
+    while (src.fill(b, batch_reads, (size_t)-1)) {
+        if (b.fq) { // a FASTQ block: what the GPU would do with it (process_qual, the >= k test) done here on the host
+            trim_block_on_host(*b.fq, k, b.start, b.stop);
+            const char *base = b.fq->text.data();
+            for (size_t r = 0; r < b.size(); r++) {
+                if (!(b.stop[r] - b.start[r] >= k)) continue;
+                fwrite(base + b.fq->acc_off[r], 1, b.fq->acc_len[r], f);
+                fprintf(f, "\t%d\t%d\t", b.start[r], b.stop[r]);
+                fwrite(base + b.fq->recs[r].seq_off, 1, b.fq->recs[r].seq_len, f);
+                fputc('\n', f);
+            }
+            continue;
+        }
         for (size_t r = 0; r < b.size(); r++) {
             fprintf(f, "%s\t%d\t%d\t", b.acc[r].c_str(), b.start[r], b.stop[r]);
             fwrite(b.bases.data() + b.offsets[r], 1, (size_t)(b.offsets[r + 1] - b.offsets[r]), f);
             fputc('\n', f);
         }
+    }
     src.close();
 }
 

@@ -4,6 +4,7 @@
 #include <functional>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kid_host.h"
@@ -30,8 +31,11 @@ struct Engine {
 
 // tree + probes, from the binary cache when `cache_path` names a valid one, else from the text files
 // (and the cache is written for the next run).  `from_cache` reports which way it went.
+// `threads`: parse workers of the probes text (0: one per core, at most 8).  `cache_writer`: if given, a cache that has
+// to be (re)written is written on that thread -- join it before `parent` / `ps` go away.
 void load_database(const std::string &tree_path, const std::string &probes_path, const std::string &cache_path, int k, int ntar,
-                   std::vector<int32_t> &parent, ProbeSet &ps, bool *from_cache = nullptr);
+                   std::vector<int32_t> &parent, ProbeSet &ps, bool *from_cache = nullptr, int threads = 0,
+                   StartupTiming *timing = nullptr, std::thread *cache_writer = nullptr);
 
 // Hashtable + Tree1 onto the GPU.  Returns false where the reference prints "out of memory in table"
 // and exits with 1 (newkmer_10nx.cpp:256-260).
@@ -67,7 +71,7 @@ long long run_file(Engine &e, Prefetcher &pf, size_t index, ReadSaver &saver);
 
 // --dry-run support (host stages only, no GPU): what WOULD be handed to the GPU, as text
 void dry_dump_db(FILE *f, const std::vector<int32_t> &parent, const ProbeSet &ps);
-void dry_dump_source(FILE *f, const std::string &label, ReadSource &src, size_t batch_reads);
+void dry_dump_source(FILE *f, const std::string &label, ReadSource &src, size_t batch_reads, int k);
 
 // gcount / ucount of the sample -> "<i>,<g>,<u>" lines
 void finish_sample(Engine &e, const std::string &result_path);

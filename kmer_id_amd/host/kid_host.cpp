@@ -3,15 +3,30 @@
 #include "kid_host.h"
 
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <zlib.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <fstream>
+#include <mutex>
 #include <sstream>
+#include <thread>
+
+#include "kid_textio.h"
 
 namespace kidhost {
 
 static const size_t REF_LINE_LIMIT = 0x4000; // BUFLEN, newkmer_10nx.cpp:85
+
+void *huge_map(size_t nbytes)
+{
+    void *p = mmap(nullptr, nbytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    return p == MAP_FAILED ? nullptr : p;
+}
+void huge_unmap(void *p, size_t nbytes) { munmap(p, nbytes); }
 
 // ---------------------------------------------------------------- tree / strain list
 std::vector<int32_t> load_tree(const std::string &path, int ntar)
@@ -120,7 +135,15 @@ static inline bool fast_uint(const char *&p, const char *e, uint32_t &out)
     return true;
 }
 
-static void roll_probe(const char *seq, size_t len, uint32_t target, int k, ProbeSet &ps)
+namespace {
+struct ProbeChunk { // what one block of lines parses to: a worker's own buffers, reused from block to block
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> targets;
+    long long lines_parsed = 0;
+};
+}
+
+static void roll_probe(const char *seq, size_t len, uint32_t target, int k, ProbeChunk &ps)
 {
     // process_kmer, :619-661: forward key, upper-case ACGT only, every full window is inserted
     const uint64_t mask = (1ULL << (2 * k)) - 1;
@@ -145,20 +168,28 @@ static void roll_probe(const char *seq, size_t len, uint32_t target, int k, Prob
     }
 }
 
-ProbeSet load_probes_gz(const std::string &path, int k)
+// one block of whole lines -> entries (the per-line work of process_kmergz, :680-705)
+static void parse_probe_block(const char *text, size_t nbytes, int k, ProbeChunk &ps)
 {
-    ProbeSet ps;
-    GzLines in(path);
-    const char *line;
-    size_t len;
+    ps.keys.clear();
+    ps.targets.clear();
+    ps.lines_parsed = 0;
     std::string tmp, sequence;
-    while (in.next(line, len)) {
+    const char *p0 = text, *end = text + nbytes;
+    while (p0 < end) {
+        const char *nl = (const char *)memchr(p0, '\n', (size_t)(end - p0));
+        if (!nl) break; // (blocks end with a newline)
+        size_t len = (size_t)(nl - p0);
+        if (len >= REF_LINE_LIMIT) throw Fatal{255, "Buffer to small for input line lengths"};
+        const char *line = p0;
+        p0 = nl + 1;
+        if (len > 0 && line[len - 1] == '\r') len--;
         if (len == 0) continue;
         // fast path: SEQ,uint,uint,uint,char,uint with nothing else on the line
         const char *p = line, *e = line + len;
         const char *s0 = p;
         while (p < e && *p != ',' && !is_ws(*p)) p++;
-        uint32_t target, org, position, count;
+        uint32_t target = 0, org, position, count;
         bool ok = (p > s0 && p < e && *p == ',');
         const char *s1 = p;
         if (ok) { p++; ok = fast_uint(p, e, target) && p < e && *p == ','; }
@@ -184,7 +215,106 @@ ProbeSet load_probes_gz(const std::string &path, int k)
             ps.lines_parsed++;
         }
     }
-    in.close();
+}
+
+ProbeSet load_probes_gz(const std::string &path, int k, int threads, StartupTiming *timing)
+{
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (threads <= 0) {
+        threads = (int)std::thread::hardware_concurrency();
+        if (threads > 8) threads = 8;
+    }
+    if (threads < 1) threads = 1;
+    GzLineBlocks in(path, (size_t)8 << 20, (size_t)threads + 2); // (its constructor throws if the file cannot be opened: exit 255 like the reference)
+    // The entries go straight into their final place: address space for as many as the library takes (2^32 - 2) is
+    // reserved, a worker parses a block into its own small buffers and then, in block order, claims the next
+    // `count` places and copies them in.  No growing arrays, no final concatenation of 1.3 GB.
+    ProbeSet ps;
+    size_t cap = (size_t)1 << 32;
+    while (cap >= ((size_t)1 << 20) && !(ps.keys.reserve(cap) && ps.targets.reserve(cap))) cap >>= 1;
+    if (cap < ((size_t)1 << 20)) throw Fatal{1, "out of address space for the database entries"};
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::pair<size_t, TextBlock>> work;
+    bool no_more = false;
+    size_t committed = 0, n_entries = 0; // blocks whose places are claimed; places claimed so far
+    size_t fail_block = (size_t)-1;
+    long long lines_parsed = 0;
+    Fatal failure{0, ""};
+    auto worker = [&]() {
+        ProbeChunk out;
+        for (;;) {
+            std::pair<size_t, TextBlock> job;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return !work.empty() || no_more; });
+                if (work.empty()) return;
+                job = std::move(work.front());
+                work.pop_front();
+                cv.notify_all();
+            }
+            bool bad = false;
+            Fatal f{0, ""};
+            try { parse_probe_block(job.second.data(), job.second.len, k, out); }
+            catch (const Fatal &e) { bad = true; f = e; out.keys.clear(); out.targets.clear(); out.lines_parsed = 0; }
+            in.recycle(job.second);
+            size_t at;
+            bool place;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return committed == job.first; });
+                if (bad && job.first < fail_block) { fail_block = job.first; failure = f; }
+                if (n_entries + out.keys.size() > cap && fail_block == (size_t)-1) {
+                    fail_block = job.first;
+                    failure = Fatal{1, "out of memory in table "}; // more entries than any table holds (newkmer_10nx.cpp:256-260)
+                }
+                at = n_entries;
+                place = fail_block == (size_t)-1;
+                if (place) { n_entries += out.keys.size(); lines_parsed += out.lines_parsed; }
+                committed++;
+                cv.notify_all();
+            }
+            if (place && !out.keys.empty()) {
+                memcpy(ps.keys.data() + at, out.keys.data(), out.keys.size() * sizeof(uint64_t));
+                memcpy(ps.targets.data() + at, out.targets.data(), out.targets.size() * sizeof(uint32_t));
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++) pool.emplace_back(worker);
+    size_t n_blocks = 0;
+    uint64_t text_bytes = 0;
+    try {
+        for (;;) {
+            TextBlock block;
+            if (!in.next(block)) break;
+            text_bytes += block.len;
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return work.size() < (size_t)threads; }); // bounded: the inflate thread sets the pace
+            work.emplace_back(n_blocks++, std::move(block));
+            cv.notify_all();
+        }
+        in.close();
+    } catch (const Fatal &e) { // a gz error / an over-long line found while cutting: behind every block handed out so far
+        std::lock_guard<std::mutex> lk(m);
+        if (n_blocks < fail_block) { fail_block = n_blocks; failure = e; }
+    }
+    {
+        std::lock_guard<std::mutex> lk(m);
+        no_more = true;
+        cv.notify_all();
+    }
+    for (std::thread &t : pool) t.join();
+    if (fail_block != (size_t)-1) throw failure; // (the first failure in file order, as the sequential reader would have met it)
+    ps.keys.set_size(n_entries);
+    ps.targets.set_size(n_entries);
+    ps.lines_parsed = lines_parsed;
+    if (timing) {
+        timing->inflate_s = in.inflate_seconds();
+        timing->parse_wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        timing->parse_threads = threads;
+        timing->text_bytes = text_bytes;
+    }
     return ps;
 }
 
@@ -220,10 +350,10 @@ bool load_db_cache(const std::string &cache_path, const std::string &tree_path, 
               memcmp(h.stamp, stamp, sizeof(stamp)) == 0 && stamp[2] != 0;
     if (ok) {
         parent.resize((size_t)ntar);
-        ps.keys.resize(h.n_entries);
-        ps.targets.resize(h.n_entries);
+        ok = ps.keys.reserve(h.n_entries) && ps.targets.reserve(h.n_entries);
+        if (ok) { ps.keys.set_size(h.n_entries); ps.targets.set_size(h.n_entries); }
         ps.lines_parsed = h.lines_parsed;
-        ok = fread(parent.data(), sizeof(int32_t), (size_t)ntar, f) == (size_t)ntar &&
+        ok = ok && fread(parent.data(), sizeof(int32_t), (size_t)ntar, f) == (size_t)ntar &&
              fread(ps.keys.data(), sizeof(uint64_t), h.n_entries, f) == h.n_entries &&
              fread(ps.targets.data(), sizeof(uint32_t), h.n_entries, f) == h.n_entries;
     }
@@ -281,32 +411,75 @@ bool trim_read(const std::string &seq, const std::string &qual, int k, int &star
 }
 
 // ---------------------------------------------------------------- FASTQ stream
-FastqStream::FastqStream(const std::string &path, int k) : lines_(path), k_(k) {}
+FastqStream::FastqStream(const std::string &path, int k, size_t block_bytes) : in_(path, block_bytes), k_(k) {}
 
-bool FastqStream::fill(ReadBatch &out, size_t max_reads, size_t max_bases)
+bool FastqStream::fill(ReadBatch &out, size_t, size_t)
 {
     out.clear();
-    const char *line;
-    size_t len;
-    std::string qual;
-    while (out.size() < max_reads && out.bases.size() < max_bases && lines_.next(line, len)) {
-        if (len == 0) continue; // blank lines do not advance the record phase (:788)
-        if (mod4_ == 1) seq_.assign(line, len);
-        else if (mod4_ == 0) acc_.assign(line, len);
-        else if (mod4_ == 3) {
-            qual.assign(line, len);
-            int st, sp;
-            if (trim_read(seq_, qual, k_, st, sp)) {
-                out.bases.insert(out.bases.end(), seq_.begin(), seq_.end());
-                out.offsets.push_back(out.bases.size());
-                out.start.push_back(st);
-                out.stop.push_back(sp);
-                out.acc.push_back(acc_);
+    for (;;) {
+        std::unique_ptr<FastqBlock> fb(new FastqBlock());
+        if (!in_.next(fb->text)) return false; // (lines of an unfinished record at the end of the file: never a read, :790-802)
+        const auto t0 = std::chrono::steady_clock::now();
+        if (!carry_.empty()) { fb->text.prepend(carry_.data(), carry_.size()); carry_.clear(); }
+        const char *const base = fb->text.data(), *const end = base + fb->text.len;
+        if (fb->text.len >= 0xFFFFFFFFull) throw Fatal{255, "FASTQ block of 4 GiB or more"};
+        fb->recs.reserve(fb->text.len / 300 + 16);
+        fb->acc_off.reserve(fb->text.len / 300 + 16);
+        fb->acc_len.reserve(fb->text.len / 300 + 16);
+        const char *p = base, *rec_start = base;
+        int phase = 0;
+        kid_fastq_rec rc{0, 0, 0, 0};
+        uint32_t a_off = 0, a_len = 0;
+        while (p < end) {
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+            if (!nl) break; // (blocks end with a newline)
+            size_t l = (size_t)(nl - p);
+            if (l >= REF_LINE_LIMIT) throw Fatal{255, "Buffer to small for input line lengths"};
+            if (l > 0 && p[l - 1] == '\r') l--;
+            if (l > 0) { // blank lines do not advance the record phase (:788)
+                switch (phase) {
+                case 0: rec_start = p; a_off = (uint32_t)(p - base); a_len = (uint32_t)l; break;
+                case 1: rc.seq_off = (uint32_t)(p - base); rc.seq_len = (uint32_t)l; break;
+                case 3:
+                    rc.qual_off = (uint32_t)(p - base);
+                    rc.qual_len = (uint32_t)l;
+                    fb->recs.push_back(rc);
+                    fb->acc_off.push_back(a_off);
+                    fb->acc_len.push_back(a_len);
+                    break;
+                default: break;
+                }
+                phase = (phase + 1) & 3;
+                if (phase == 0) rec_start = nl + 1;
             }
+            p = nl + 1;
         }
-        mod4_ = (mod4_ + 1) % 4;
+        // an unfinished record goes in front of the next block
+        fb->used = (size_t)(rec_start - base);
+        if (phase != 0) carry_.assign(rec_start, end);
+        else fb->used = fb->text.len;
+        index_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (fb->recs.empty()) { in_.recycle(fb->text); continue; } // (a block of blank lines, or one piece of a huge record)
+        out.fq = std::move(fb);
+        return true;
     }
-    return out.size() > 0;
+}
+
+void trim_block_on_host(const FastqBlock &b, int k, std::vector<int32_t> &start, std::vector<int32_t> &stop)
+{
+    const size_t n = b.recs.size();
+    start.resize(n);
+    stop.resize(n);
+    const char *base = b.text.data();
+    std::string seq, qual;
+    for (size_t r = 0; r < n; r++) {
+        seq.assign(base + b.recs[r].seq_off, b.recs[r].seq_len);
+        qual.assign(base + b.recs[r].qual_off, b.recs[r].qual_len);
+        int st, sp;
+        trim_read(seq, qual, k, st, sp);
+        start[r] = st;
+        stop[r] = sp;
+    }
 }
 
 // ---------------------------------------------------------------- FASTA(.gz)
@@ -428,22 +601,36 @@ ReadSaver::~ReadSaver()
 
 static void write_saved(FILE *f, uint32_t t, const ReadBatch &b, size_t r)
 {
-    const uint8_t *s = b.bases.data() + b.offsets[r] + b.start[r];
+    const char *acc, *s;
+    size_t acc_len;
+    if (b.fq) {
+        acc = b.fq->text.data() + b.fq->acc_off[r];
+        acc_len = b.fq->acc_len[r];
+        s = b.fq->text.data() + b.fq->recs[r].seq_off + b.start[r];
+    } else {
+        acc = b.acc[r].data();
+        acc_len = b.acc[r].size();
+        s = (const char *)b.bases.data() + b.offsets[r] + b.start[r];
+    }
     fprintf(f, ">%u:", t);
-    fwrite(b.acc[r].data(), 1, b.acc[r].size(), f);
+    fwrite(acc, 1, acc_len, f);
     fputc('\n', f);
     fwrite(s, 1, (size_t)(b.stop[r] - b.start[r] + 1), f);
     fputc('\n', f);
 }
 
-void ReadSaver::add_batch(const ReadBatch &b, const std::vector<uint32_t> &final_targ)
+long long ReadSaver::add_batch(const ReadBatch &b, const std::vector<uint32_t> &final_targ, int k)
 {
+    long long handed = 0;
     for (size_t r = 0; r < b.size(); r++) {
+        if (b.fq && !(b.stop[r] - b.start[r] >= k)) continue; // dropped by process_qual (:757): never reached process_read
+        handed++;
         const uint32_t t = final_targ[r];
         if (t > 1 && seen_[t] < 12 && f_ && first12_enabled_) write_saved(f_, t, b, r); // SAVENUM, :48,:608
         if (t > 1 && t == save_target_ && f2_) write_saved(f2_, t, b, r);
         seen_[t]++;
     }
+    return handed;
 }
 
 // ---------------------------------------------------------------- job lists (kmer_read_vf6.cpp:1021-1057)

@@ -7,15 +7,14 @@
 
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
+
+#include "kid_textio.h"
+#include "kmer_id_amd.h"
 
 namespace kidhost {
 
-// What the reference does when it gives up (newkmer_10nx.cpp:87-91 and friends)
-struct Fatal {
-    int exit_code;
-    std::string message;
-};
 
 // ---------------------------------------------------------------- database text files
 // Tree1 after `linestream >> i >> j; add_edge(i,j)` over every line (newkmer_10nx.cpp:973-983).
@@ -25,13 +24,67 @@ std::vector<int32_t> load_tree(const std::string &path, int ntar);
 // strain list (newkmer_10nx.cpp:951-971): only its presence is observable ("narin <name>")
 bool strain_list_present(const std::string &path);
 
+// A flat array whose final size is not known while it is being filled by several threads (the entries of a 5 GB
+// probes file): address space for the most it can ever hold is reserved once (anonymous, no-reserve mapping: only the
+// pages that are written cost memory), so it never moves and is never copied.
+template <class T>
+class HugeVec {
+public:
+    HugeVec() {}
+    ~HugeVec() { release(); }
+    HugeVec(const HugeVec &) = delete;
+    HugeVec &operator=(const HugeVec &) = delete;
+    HugeVec(HugeVec &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+    HugeVec &operator=(HugeVec &&o) noexcept
+    {
+        if (this != &o) { release(); p_ = o.p_; n_ = o.n_; cap_ = o.cap_; o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+        return *this;
+    }
+    bool reserve(size_t cap); // false: the mapping was refused
+    void set_size(size_t n) { n_ = n; }
+    size_t size() const { return n_; }
+    size_t capacity() const { return cap_; }
+    T *data() { return p_; }
+    const T *data() const { return p_; }
+    const T &operator[](size_t i) const { return p_[i]; }
+private:
+    void release();
+    T *p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+};
+void *huge_map(size_t nbytes);
+void huge_unmap(void *p, size_t nbytes);
+template <class T> bool HugeVec<T>::reserve(size_t cap)
+{
+    release();
+    if (cap == 0) return true;
+    p_ = static_cast<T *>(huge_map(cap * sizeof(T)));
+    cap_ = p_ ? cap : 0;
+    return p_ != nullptr;
+}
+template <class T> void HugeVec<T>::release()
+{
+    if (p_) huge_unmap(p_, cap_ * sizeof(T));
+    p_ = nullptr;
+    n_ = cap_ = 0;
+}
 struct ProbeSet {
-    std::vector<uint64_t> keys;    // forward keys in file order (process_kmer, :619-661)
-    std::vector<uint32_t> targets;
+    HugeVec<uint64_t> keys;    // forward keys in file order (process_kmer, :619-661)
+    HugeVec<uint32_t> targets;
     long long lines_parsed = 0;    // tct, printed as "<n> kmers loaded" (:701,:989)
 };
-// process_kmergz (newkmer_10nx.cpp:663-712).  Throws Fatal{255} on gz errors / over-long lines.
-ProbeSet load_probes_gz(const std::string &path, int k);
+// Wall-clock seconds of the start-up phases, for --timing (nk10 prints them to stderr as one JSON line)
+struct StartupTiming {
+    double inflate_s = 0;      // inside gzread (the inflate thread; overlaps the parse)
+    double parse_wall_s = 0;   // probes text -> keys: inflate + parse workers, wall
+    double cache_read_s = 0, cache_write_s = 0;
+    double gpu_build_s = 0;    // kid_db_build: upload + table build on the GPU
+    int parse_threads = 0;
+    uint64_t text_bytes = 0;
+};
+// process_kmergz (newkmer_10nx.cpp:663-712).  One thread inflates, `threads` workers parse blocks of whole lines, the
+// entries come out in file order.  Throws Fatal{255} on gz errors / over-long lines.  threads <= 0: one per core, at most 8
+ProbeSet load_probes_gz(const std::string &path, int k, int threads = 0, StartupTiming *timing = nullptr);
 
 // Binary cache of the parsed database: what load_tree + load_probes_gz produce, so that a
 // later run skips the text parse (minutes for 108 M lines).  The cache is tied to the size and
@@ -64,13 +117,23 @@ private:
     bool fill();
 };
 
+// A block of FASTQ text cut at a record boundary, with the lines of its records found (FastqStream): what the host
+// does of process_fqgz.  Trimming and classification of the block happen on the GPU (kid_classify_fastq_async).
+struct FastqBlock {
+    TextBlock text;
+    size_t used = 0;                     // bytes of whole records at the front of `text`
+    std::vector<kid_fastq_rec> recs;     // per record: sequence line and quality line (offsets into text.data())
+    std::vector<uint32_t> acc_off, acc_len; // ... and its header line (with the leading '@'), for _reads.txt
+};
+
 struct ReadBatch {
     std::vector<uint8_t> bases;     // whole sequence lines, concatenated
     std::vector<uint64_t> offsets;  // n+1
-    std::vector<int32_t> start, stop;
+    std::vector<int32_t> start, stop; // process_qual's range per read (FASTQ blocks: filled in by the GPU)
     std::vector<std::string> acc;   // header lines (with the leading '@'), for _reads.txt
-    size_t size() const { return start.size(); }
-    void clear() { bases.clear(); offsets.assign(1, 0); start.clear(); stop.clear(); acc.clear(); }
+    std::unique_ptr<FastqBlock> fq; // set: the batch is a FASTQ text block, the vectors above are not used (start / stop receive results)
+    size_t size() const { return fq ? fq->recs.size() : start.size(); }
+    void clear() { bases.clear(); offsets.assign(1, 0); start.clear(); stop.clear(); acc.clear(); fq.reset(); }
 };
 
 // A file of reads delivered as batches.  fill() clears `out`, appends reads until max_reads reads or
@@ -82,18 +145,26 @@ public:
     virtual void close() {}
 };
 
-// process_fqgz (newkmer_10nx.cpp:762-816): FASTQ(.gz), quality-trimmed by process_qual
+// process_fqgz (newkmer_10nx.cpp:762-816): FASTQ(.gz).  One thread inflates (GzLineBlocks), fill() finds the lines of
+// a block under the reference's rules -- split at '\n', one trailing '\r' removed, empty lines skipped without
+// advancing the 4-line phase (:788), the unterminated last line dropped, a line of 16384 bytes or more fatal -- and
+// hands the block on as it is: a batch is one FastqBlock.  (max_reads / max_bases are not used: the block size set at
+// construction bounds a batch.)
 class FastqStream : public ReadSource {
 public:
-    FastqStream(const std::string &path, int k);
+    FastqStream(const std::string &path, int k, size_t block_bytes = (size_t)8 << 20);
     bool fill(ReadBatch &out, size_t max_reads, size_t max_bases = (size_t)-1) override;
-    void close() override { lines_.close(); }
+    void close() override { in_.close(); }
+    double inflate_seconds() const { return in_.inflate_seconds(); }
+    double index_seconds() const { return index_s_; }
 private:
-    GzLines lines_;
+    GzLineBlocks in_;
     int k_;
-    int mod4_ = 0;
-    std::string seq_, acc_;
+    std::vector<char> carry_; // the lines of an unfinished record at the end of the block before
+    double index_s_ = 0;
 };
+// process_qual on the host for the records of a block (the --dry-run dump, and tests): start / stop per record
+void trim_block_on_host(const FastqBlock &b, int k, std::vector<int32_t> &start, std::vector<int32_t> &stop);
 
 // process_fagz (newkmer_10nx.cpp:818-875, kmer_read_vf6.cpp:803-861): FASTA(.gz), multi-line records
 // joined, a record is classified whole if it is longer than k
@@ -162,7 +233,9 @@ public:
     ReadSaver(const std::string &first12_path, int ntar, const std::string &target_path = "", uint32_t save_target = 0,
               bool first12_enabled = true);
     ~ReadSaver();
-    void add_batch(const ReadBatch &b, const std::vector<uint32_t> &final_targ);
+    // returns the number of reads of the batch that the reference hands to process_read (all of them, except in a FASTQ
+    // block: there the records process_qual drops are still in the batch, with stop - start < k)
+    long long add_batch(const ReadBatch &b, const std::vector<uint32_t> &final_targ, int k);
 private:
     FILE *f_ = nullptr, *f2_ = nullptr;
     uint32_t save_target_ = 0;

@@ -1,0 +1,166 @@
+// kid_textio.cpp -- see kid_textio.h
+#include "kid_textio.h"
+
+#include <string.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+namespace kidhost {
+
+static const size_t REF_LINE_LIMIT = 0x4000; // BUFLEN, newkmer_10nx.cpp:85
+static const size_t HEAD = TextBlock::kHeadroomForLine + TextBlock::kHeadroomForRecords;
+
+void TextBlock::prepend(const char *p, size_t n)
+{
+    if (n > off) throw Fatal{255, "Buffer to small for input line lengths"}; // (a record of lines that long: the reference gave up at the first)
+    off -= n;
+    len += n;
+    memcpy(buf.data() + off, p, n);
+}
+
+struct GzLineBlocks::Impl {
+    gzFile gz = nullptr;
+    size_t chunk_bytes, depth;
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<TextBlock> full;
+    std::deque<std::vector<char>> spare;
+    bool done = false, stop = false, failed = false;
+    Fatal failure{0, ""};
+    std::atomic<uint64_t> ns_inflate{0}, bytes{0};
+
+    void fail(const Fatal &f)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        failed = true;
+        failure = f;
+        done = true;
+        cv.notify_all();
+    }
+
+    void run()
+    {
+        std::vector<char> carry; // the unfinished last line of the chunk before
+        for (;;) {
+            TextBlock b;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || full.size() < depth; });
+                if (stop) return;
+                if (!spare.empty()) { b.buf = std::move(spare.front()); spare.pop_front(); }
+            }
+            if (b.buf.size() < HEAD + chunk_bytes) b.buf.resize(HEAD + chunk_bytes);
+            const auto t0 = std::chrono::steady_clock::now();
+            const int got = gzread(gz, b.buf.data() + HEAD, (unsigned)chunk_bytes);
+            ns_inflate += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (got < 0) {
+                int err = 0;
+                const char *msg = gzerror(gz, &err);
+                fail(Fatal{255, msg ? msg : "gzread failed"});
+                return;
+            }
+            if (got == 0) { // end of file: the unterminated tail is dropped (:812-813) -- unless the reference's buffer had overflowed on it first
+                if (carry.size() >= REF_LINE_LIMIT) { fail(Fatal{255, "Buffer to small for input line lengths"}); return; }
+                std::lock_guard<std::mutex> lk(m);
+                done = true;
+                cv.notify_all();
+                return;
+            }
+            bytes += (uint64_t)got;
+            char *base = b.buf.data() + HEAD;
+            const char *last = (const char *)memrchr(base, '\n', (size_t)got);
+            if (!last) { // no line ends in this chunk
+                carry.insert(carry.end(), base, base + got);
+                if (carry.size() >= REF_LINE_LIMIT) { fail(Fatal{255, "Buffer to small for input line lengths"}); return; }
+                std::lock_guard<std::mutex> lk(m);
+                spare.push_back(std::move(b.buf));
+                continue;
+            }
+            const size_t head = (size_t)(last - base) + 1, tail = (size_t)got - head;
+            // (carry < 16 KiB here: a longer one ended the run above)
+            b.off = HEAD - carry.size();
+            b.len = carry.size() + head;
+            if (!carry.empty()) memcpy(b.buf.data() + b.off, carry.data(), carry.size());
+            carry.assign(base + head, base + head + tail);
+            const bool too_long = carry.size() >= REF_LINE_LIMIT;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                full.push_back(std::move(b));
+                cv.notify_all();
+            }
+            if (too_long) { fail(Fatal{255, "Buffer to small for input line lengths"}); return; }
+        }
+    }
+};
+
+GzLineBlocks::GzLineBlocks(const std::string &path, size_t block_bytes, size_t depth) : impl_(new Impl())
+{
+    impl_->gz = gzopen(path.c_str(), "rb");
+    // gzopen failure: the reference calls gzread(NULL) -> -1 -> error(gzerror(NULL)) -> exit(255)
+    if (!impl_->gz) throw Fatal{255, "cannot open " + path};
+    gzbuffer(impl_->gz, 1 << 20);
+    impl_->chunk_bytes = block_bytes < 2 * REF_LINE_LIMIT ? 2 * REF_LINE_LIMIT : block_bytes;
+    impl_->depth = depth < 1 ? 1 : depth;
+    impl_->th = std::thread([this] { impl_->run(); });
+}
+
+GzLineBlocks::~GzLineBlocks()
+{
+    {
+        std::lock_guard<std::mutex> lk(impl_->m);
+        impl_->stop = true;
+        impl_->cv.notify_all();
+    }
+    if (impl_->th.joinable()) impl_->th.join();
+    if (impl_->gz) gzclose(impl_->gz);
+}
+
+bool GzLineBlocks::next(TextBlock &b)
+{
+    std::unique_lock<std::mutex> lk(impl_->m);
+    impl_->cv.wait(lk, [&] { return !impl_->full.empty() || impl_->done; });
+    if (!impl_->full.empty()) {
+        if (!b.buf.empty()) impl_->spare.push_back(std::move(b.buf));
+        b = std::move(impl_->full.front());
+        impl_->full.pop_front();
+        impl_->cv.notify_all();
+        return true;
+    }
+    if (impl_->failed) throw impl_->failure;
+    return false;
+}
+
+void GzLineBlocks::recycle(TextBlock &b)
+{
+    if (b.buf.empty()) return;
+    std::lock_guard<std::mutex> lk(impl_->m);
+    impl_->spare.push_back(std::move(b.buf));
+    b = TextBlock();
+}
+
+void GzLineBlocks::close()
+{
+    {
+        std::lock_guard<std::mutex> lk(impl_->m);
+        impl_->stop = true;
+        impl_->cv.notify_all();
+    }
+    if (impl_->th.joinable()) impl_->th.join();
+    if (impl_->gz) {
+        const int rc = gzclose(impl_->gz);
+        impl_->gz = nullptr;
+        if (rc != Z_OK) throw Fatal{255, "failed gzclose"};
+    }
+}
+
+double GzLineBlocks::inflate_seconds() const { return (double)impl_->ns_inflate.load() * 1e-9; }
+uint64_t GzLineBlocks::bytes_out() const { return impl_->bytes.load(); }
+
+} // namespace kidhost

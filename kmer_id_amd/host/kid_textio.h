@@ -1,0 +1,55 @@
+// kid_textio.h -- gzip text input as a pipeline: one thread inflates and cuts the text into blocks of whole lines, the
+// consumers work on the blocks in parallel (probes file: parse workers; FASTQ: the record indexer).  zlib inflates a
+// stream at 0.2-0.5 GB/s of text on one core and cannot be split; everything behind it can.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace kidhost {
+
+// What the reference does when it gives up (newkmer_10nx.cpp:87-91 and friends)
+struct Fatal {
+    int exit_code;
+    std::string message;
+};
+
+// A block of whole lines inside a recycled buffer.  The bytes before `off` are headroom: a consumer that carries an
+// unfinished record over from the block before copies it there (prepend) instead of copying the block.
+struct TextBlock {
+    std::vector<char> buf;
+    size_t off = 0, len = 0;
+    const char *data() const { return buf.data() + off; }
+    char *data() { return buf.data() + off; }
+    // put `n` bytes in front of the block (n <= kHeadroomForRecords)
+    void prepend(const char *p, size_t n);
+    static const size_t kHeadroomForLine = 0x4000;        // the inflater's own carry: the unfinished last line of a chunk
+    static const size_t kHeadroomForRecords = 4 * 0x4000; // a consumer's carry: up to three lines of an unfinished record
+};
+
+// A thread that inflates one .gz file (or reads a plain file: gzread passes those through) and hands out its text in
+// blocks that end with a '\n'.  The rules of the reference's reader (newkmer_10nx.cpp:762-816) that concern raw text:
+// a line of 16384 bytes or more is fatal (exit 255, :773), the unterminated tail of the file is dropped (:812-813).
+// Failures surface in stream order: next() throws Fatal{255} where the reference's gzread loop would have called
+// error() (:87-91, :772-778), after every block before the failure has been handed out.
+class GzLineBlocks {
+public:
+    explicit GzLineBlocks(const std::string &path, size_t block_bytes = (size_t)8 << 20, size_t depth = 4);
+    ~GzLineBlocks();
+    GzLineBlocks(const GzLineBlocks &) = delete;
+    GzLineBlocks &operator=(const GzLineBlocks &) = delete;
+    // the next block (swapped into `b`, whose old buffer is recycled); false at the end of the file
+    bool next(TextBlock &b);
+    void recycle(TextBlock &b);      // give a buffer back without asking for the next block
+    void close();                    // gzclose; throws Fatal{255} "failed gzclose"
+    double inflate_seconds() const;  // time spent inside gzread so far
+    uint64_t bytes_out() const;
+private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+} // namespace kidhost

@@ -103,7 +103,7 @@ int main(int argc, char **argv)
             for (const std::string &name : {r1name, r2name}) {
                 if (name.empty() || name == "none") continue;
                 std::unique_ptr<ReadSource> src = open_by_suffix(name, k, nullptr);
-                if (src) dry_dump_source(f, name, *src, batch_reads);
+                if (src) dry_dump_source(f, name, *src, batch_reads, k);
             }
             fclose(f);
             return 0;

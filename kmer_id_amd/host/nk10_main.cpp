@@ -14,6 +14,8 @@
 //   --fasta          the reference's compile-time FASTQ=0 mode (:28,:1032-1035): one plain FASTA file
 //                    <prefix><r1 suffix> per sample, read by process_fa (:877-913), no R2 file
 //   --db-cache FILE  binary cache of the parsed database: read if valid, (re)written otherwise
+//   --timing         one JSON line on stderr when the run ends: seconds of the start-up phases (probes inflate / parse,
+//                    cache read / write, upload + table build on the GPU, first batch classified) and of the read files
 //   --dry-run FILE   host stages only (no GPU): parse the DB text files and the FASTQ files,
 //                    write what WOULD be handed to the GPU to FILE (used by the CPU test-suite)
 #include <dirent.h>
@@ -21,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <iostream>
@@ -40,6 +43,9 @@ int main(int argc, char **argv)
     std::string dry_run, db_cache, device_list;
     bool fasta_mode = false;
     bool parse_only = false; // --parse-only: run the reader pool over the directory without a GPU and report its rate
+    bool timing = false;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since_start = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&](const char *name) -> const char * {
@@ -60,6 +66,7 @@ int main(int argc, char **argv)
         else if (a == "--db-cache") db_cache = val("--db-cache");
         else if (a == "--parse-only") parse_only = true;
         else if (a == "--fasta") fasta_mode = true;
+        else if (a == "--timing") timing = true;
         else if (dname.empty()) dname = a;
         else { std::cerr << "nk10: unexpected argument " << a << "\n"; return 2; }
     }
@@ -86,7 +93,24 @@ int main(int argc, char **argv)
         }
         std::vector<int32_t> parent;
         ProbeSet ps;
-        load_database(tpath, pname, db_cache, k, ntar, parent, ps);
+        StartupTiming tm;
+        bool from_cache = false;
+        std::thread cache_writer; // (a cache that has to be written is written beside the upload and the table build)
+        struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } join_cache_writer{cache_writer};
+        load_database(tpath, pname, db_cache, k, ntar, parent, ps, &from_cache, threads, &tm, &cache_writer);
+        const double t_db_loaded = since_start();
+        double t_gpu_ready = -1, t_first_file = -1;
+        size_t n_entries = ps.keys.size(), n_devices = 0;
+        auto print_timing = [&]() {
+            if (!timing) return;
+            fprintf(stderr, "{\"nk10_timing\": {\"entries\": %zu, \"from_cache\": %s, \"probes_text_bytes\": %llu, \"probes_inflate_s\": %.3f, "
+                            "\"probes_parse_wall_s\": %.3f, \"parse_threads\": %d, \"cache_read_s\": %.3f, \"cache_write_s\": %.3f, "
+                            "\"db_loaded_at_s\": %.3f, \"gpu_upload_and_build_s\": %.3f, \"gpu_ready_at_s\": %.3f, "
+                            "\"first_file_classified_at_s\": %.3f, \"total_s\": %.3f, \"log2_slots\": %d, \"devices\": %zu}}\n",
+                    n_entries, from_cache ? "true" : "false", (unsigned long long)tm.text_bytes, tm.inflate_s, tm.parse_wall_s,
+                    tm.parse_threads, tm.cache_read_s, tm.cache_write_s, t_db_loaded, tm.gpu_build_s, t_gpu_ready, t_first_file,
+                    since_start(), log2_slots, n_devices);
+        };
         std::cout << "tree loaded" << std::endl;
         std::cout << ps.lines_parsed << " kmers loaded" << std::endl;
 
@@ -107,7 +131,7 @@ int main(int argc, char **argv)
             for (const std::string &prefix : names)
                 for (const std::string &suffix : {e1, e2}) {
                     FastqStream fq(dname + prefix + suffix, k);
-                    dry_dump_source(f, prefix + suffix, fq, batch_reads);
+                    dry_dump_source(f, prefix + suffix, fq, batch_reads, k);
                 }
             fclose(f);
             return 0;
@@ -134,6 +158,8 @@ int main(int argc, char **argv)
             for (size_t f = 0; f < nf; f++)
                 while (std::unique_ptr<ReadBatch> b = pf.next(f)) { n += (long long)b->size(); bases += (long long)b->bases.size(); }
             std::cout << n << " reads, " << bases << " bases parsed" << std::endl;
+            if (cache_writer.joinable()) cache_writer.join();
+            print_timing();
             return 0;
         }
         Engine eng;
@@ -143,6 +169,10 @@ int main(int argc, char **argv)
             std::cout << "out of memory in table " << std::endl;
             return 1;
         }
+        t_gpu_ready = since_start();
+        tm.gpu_build_s = t_gpu_ready - t_db_loaded;
+        n_devices = devices.size();
+        if (cache_writer.joinable()) cache_writer.join();
         ps = ProbeSet();
 
         // ---- find the samples (:992-1014): every directory entry whose name contains the R1 suffix
@@ -196,12 +226,14 @@ int main(int argc, char **argv)
                 } else {
                     for (int mate = 0; mate < 2; mate++) {
                         tct += run_file(eng, pf, fi++, saver);
+                        if (t_first_file < 0) t_first_file = since_start();
                         std::cout << tct << " reads loaded" << std::endl;
                     }
                 }
             }
             finish_sample(eng, dname + prefix + "_result.txt");
         }
+        print_timing();
     } catch (const Fatal &f) {
         std::cerr << f.message << "\n";
         return f.exit_code;

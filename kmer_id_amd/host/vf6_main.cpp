@@ -106,7 +106,7 @@ int main(int argc, char **argv)
                 for (int i = 0; i < jobs.n_inputs(j); i++) {
                     const std::string &input = jobs.file_rows[(size_t)j][(size_t)i];
                     std::unique_ptr<ReadSource> src = open_by_suffix(input, k, nullptr);
-                    if (src) dry_dump_source(f, jobs.header_name[(size_t)j] + " " + input, *src, batch_reads);
+                    if (src) dry_dump_source(f, jobs.header_name[(size_t)j] + " " + input, *src, batch_reads, k);
                 }
             fclose(f);
             return 0;
