@@ -199,6 +199,105 @@ std::unique_ptr<ReadBatch> Prefetcher::next(size_t index)
     return nullptr;
 }
 
+std::unique_ptr<ReadBatch> Prefetcher::next_any(size_t lo, size_t hi, size_t &which)
+{
+    std::unique_lock<std::mutex> lk(impl_->m);
+    for (;;) {
+        bool all_done = true;
+        for (size_t i = lo; i < hi; i++) {
+            Impl::Slot &s = impl_->slots[i];
+            if (!s.q.empty()) {
+                std::unique_ptr<ReadBatch> b = std::move(s.q.front());
+                s.q.pop_front();
+                impl_->cv.notify_all();
+                which = i;
+                return b;
+            }
+            if (!s.done) all_done = false;
+        }
+        // a failure surfaces when everything in front of it has been read to its end and handed out
+        for (size_t i = lo; i < hi; i++) {
+            Impl::Slot &s = impl_->slots[i];
+            if (!s.done) break;
+            if (s.failed) { which = i; throw s.failure; }
+        }
+        if (all_done) return nullptr;
+        impl_->cv.wait(lk);
+    }
+}
+
+void run_files_together(Engine &e, Prefetcher &pf, size_t first, size_t count, ReadSaver &saver, std::vector<long long> &handed,
+                        const std::function<void(size_t)> &done)
+{
+    struct InFlight {
+        std::unique_ptr<ReadBatch> batch;
+        std::vector<uint32_t> final_targ;
+        uint64_t ticket = 0;
+        kid_sample *sample = nullptr;
+        size_t file = 0;
+        bool last_of_file = false;
+    };
+    std::deque<InFlight> q;
+    handed.assign(count, 0);
+    const size_t max_in_flight = 2 * e.samples.size();
+    std::vector<char> ended(count, 0);   // no more batches will come from the file
+    std::vector<size_t> pending(count, 0); // batches of the file still in flight
+    size_t next_done = 0;
+    auto announce = [&]() { // files that are through, in file order
+        while (next_done < count && ended[next_done] && pending[next_done] == 0) {
+            saver.file_done(next_done);
+            done(next_done);
+            next_done++;
+        }
+    };
+    auto retire = [&]() {
+        InFlight &f = q.front();
+        int rc = kid_classify_wait(f.sample, f.ticket);
+        if (rc != KID_OK) die_kid(rc);
+        handed[f.file] += saver.add_batch_of(f.file, *f.batch, f.final_targ, e.k);
+        pending[f.file]--;
+        q.pop_front();
+        announce();
+    };
+    try {
+        for (;;) {
+            size_t which = 0;
+            std::unique_ptr<ReadBatch> b = pf.next_any(first, first + count, which);
+            if (!b) break;
+            q.emplace_back();
+            InFlight &f = q.back();
+            f.batch = std::move(b);
+            f.file = which - first;
+            pending[f.file]++;
+            const size_t nr = f.batch->size();
+            f.final_targ.resize(nr);
+            f.sample = e.samples[e.next_sample]; // batches are dealt round-robin over the devices
+            e.next_sample = (e.next_sample + 1) % e.samples.size();
+            int rc;
+            if (f.batch->fq) {
+                FastqBlock &fb = *f.batch->fq;
+                f.batch->start.resize(nr);
+                f.batch->stop.resize(nr);
+                rc = kid_classify_fastq_async(f.sample, (const uint8_t *)fb.text.data(), fb.used, fb.recs.data(), nr, f.final_targ.data(),
+                                              f.batch->start.data(), f.batch->stop.data(), &f.ticket);
+            } else {
+                rc = kid_classify_batch_async(f.sample, f.batch->bases.data(), f.batch->offsets.data(), f.batch->start.data(),
+                                              f.batch->stop.data(), nr, f.final_targ.data(), &f.ticket);
+            }
+            if (rc != KID_OK) die_kid(rc);
+            while (q.size() > max_in_flight) retire();
+        }
+    } catch (const Fatal &) {
+        // a file failed behind the batches handed out so far: those are the library's until waited for, and the
+        // reference had processed them (and every file before the failing one) before it met the failure
+        while (!q.empty()) retire();
+        throw;
+    }
+    while (!q.empty()) retire();
+    for (size_t f = 0; f < count; f++) ended[f] = 1;
+    announce();
+}
+
 long long run_file(Engine &e, Prefetcher &pf, size_t index, ReadSaver &saver)
 {
     // Two batches in flight per device: while the GPU classifies batch b, batch b + 1 is uploaded and the results of

@@ -61,6 +61,10 @@ public:
     ~Prefetcher();
     // next batch of file `index` (indices must be visited in increasing order); nullptr at its end
     std::unique_ptr<ReadBatch> next(size_t index);
+    // next batch of ANY of the files [lo, hi) -- whichever has one ready; `which` says whose.  nullptr when all of them
+    // are at their end.  A file that failed throws its Fatal only once the files before it in the range are through
+    // (the reference would have read those completely before it met the failure).
+    std::unique_ptr<ReadBatch> next_any(size_t lo, size_t hi, size_t &which);
 private:
     struct Impl;
     std::unique_ptr<Impl> impl_;
@@ -68,6 +72,12 @@ private:
 
 // classify every batch of file `index`; returns the number of reads handed to process_read
 long long run_file(Engine &e, Prefetcher &pf, size_t index, ReadSaver &saver);
+// the same for the files [first, first + count) of ONE sample, read and classified at the same time (the two mates of
+// nk10: two inflate threads instead of one after the other); the counters do not care about the order, the read saver
+// restores it.  handed[f]: reads of file first + f handed to process_read; done(f) is called when file first + f is
+// through, in file order.
+void run_files_together(Engine &e, Prefetcher &pf, size_t first, size_t count, ReadSaver &saver, std::vector<long long> &handed,
+                        const std::function<void(size_t)> &done);
 
 // --dry-run support (host stages only, no GPU): what WOULD be handed to the GPU, as text
 void dry_dump_db(FILE *f, const std::vector<int32_t> &parent, const ProbeSet &ps);

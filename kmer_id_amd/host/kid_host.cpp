@@ -599,38 +599,70 @@ ReadSaver::~ReadSaver()
     if (f2_) fclose(f2_);
 }
 
-static void write_saved(FILE *f, uint32_t t, const ReadBatch &b, size_t r)
+static void write_saved(FILE *f, uint32_t t, const char *acc, size_t acc_len, const char *seq, size_t seq_len)
 {
-    const char *acc, *s;
-    size_t acc_len;
-    if (b.fq) {
-        acc = b.fq->text.data() + b.fq->acc_off[r];
-        acc_len = b.fq->acc_len[r];
-        s = b.fq->text.data() + b.fq->recs[r].seq_off + b.start[r];
-    } else {
-        acc = b.acc[r].data();
-        acc_len = b.acc[r].size();
-        s = (const char *)b.bases.data() + b.offsets[r] + b.start[r];
-    }
     fprintf(f, ">%u:", t);
     fwrite(acc, 1, acc_len, f);
     fputc('\n', f);
-    fwrite(s, 1, (size_t)(b.stop[r] - b.start[r] + 1), f);
+    fwrite(seq, 1, seq_len, f);
     fputc('\n', f);
 }
 
-long long ReadSaver::add_batch(const ReadBatch &b, const std::vector<uint32_t> &final_targ, int k)
+// one read in the reference's order (:608-613)
+void ReadSaver::emit(uint32_t t, const char *acc, size_t acc_len, const char *seq, size_t seq_len)
+{
+    if (t > 1 && seen_[t] < 12 && f_ && first12_enabled_) write_saved(f_, t, acc, acc_len, seq, seq_len); // SAVENUM, :48,:608
+    if (t > 1 && t == save_target_ && f2_) write_saved(f2_, t, acc, acc_len, seq, seq_len);
+    seen_[t]++;
+}
+
+long long ReadSaver::add_batch_of(size_t file, const ReadBatch &b, const std::vector<uint32_t> &final_targ, int k)
 {
     long long handed = 0;
+    const bool direct = file == cur_file_;
+    if (!direct && later_.size() <= file) later_.resize(file + 1);
+    if (!direct && later_[file].count.empty()) later_[file].count.assign(seen_.size(), 0);
     for (size_t r = 0; r < b.size(); r++) {
         if (b.fq && !(b.stop[r] - b.start[r] >= k)) continue; // dropped by process_qual (:757): never reached process_read
         handed++;
         const uint32_t t = final_targ[r];
-        if (t > 1 && seen_[t] < 12 && f_ && first12_enabled_) write_saved(f_, t, b, r); // SAVENUM, :48,:608
-        if (t > 1 && t == save_target_ && f2_) write_saved(f2_, t, b, r);
-        seen_[t]++;
+        const char *acc, *s;
+        size_t acc_len;
+        if (b.fq) {
+            acc = b.fq->text.data() + b.fq->acc_off[r];
+            acc_len = b.fq->acc_len[r];
+            s = b.fq->text.data() + b.fq->recs[r].seq_off + b.start[r];
+        } else {
+            acc = b.acc[r].data();
+            acc_len = b.acc[r].size();
+            s = (const char *)b.bases.data() + b.offsets[r] + b.start[r];
+        }
+        const size_t seq_len = (size_t)(b.stop[r] - b.start[r] + 1);
+        if (direct) { emit(t, acc, acc_len, s, seq_len); continue; }
+        // a later file: only its first 12 reads of a target can be among the target's first 12 overall (and every read
+        // of the -target file's target is wanted); reads that can be neither only count -- and a count that is past 12
+        // decides nothing any more
+        if (t <= 1) continue;
+        Later &l = later_[file];
+        const bool wanted = (l.count[t] < 12 && f_ && first12_enabled_) || (t == save_target_ && f2_);
+        if (l.count[t] < 12) l.count[t]++;
+        if (wanted) l.held.push_back(Held{t, std::string(acc, acc_len), std::string(s, seq_len)});
     }
     return handed;
+}
+
+void ReadSaver::file_done(size_t file)
+{
+    if (later_.size() <= file) later_.resize(file + 1);
+    later_[file].done = true;
+    while (cur_file_ < later_.size() && later_[cur_file_].done) { // the next file's turn: what it held back, in its order
+        cur_file_++;
+        if (cur_file_ < later_.size()) {
+            for (const Held &h : later_[cur_file_].held) emit(h.t, h.acc.data(), h.acc.size(), h.seq.data(), h.seq.size());
+            later_[cur_file_].held.clear();
+            later_[cur_file_].held.shrink_to_fit();
+        }
+    }
 }
 
 // ---------------------------------------------------------------- job lists (kmer_read_vf6.cpp:1021-1057)

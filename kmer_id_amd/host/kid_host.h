@@ -235,12 +235,23 @@ public:
     ~ReadSaver();
     // returns the number of reads of the batch that the reference hands to process_read (all of them, except in a FASTQ
     // block: there the records process_qual drops are still in the batch, with stop - start < k)
-    long long add_batch(const ReadBatch &b, const std::vector<uint32_t> &final_targ, int k);
+    long long add_batch(const ReadBatch &b, const std::vector<uint32_t> &final_targ, int k) { return add_batch_of(0, b, final_targ, k); }
+    // Several files of one sample read at the same time (the two mates, nk10): the batches of file f arrive in file
+    // order, but files interleave.  What the reference writes depends on the order "all of file 0, then all of file 1":
+    // the reads of a later file that can still be among a target's first 12 (the first 12 of that target within their
+    // own file) wait in memory until the files before it are through (file_done).
+    long long add_batch_of(size_t file, const ReadBatch &b, const std::vector<uint32_t> &final_targ, int k);
+    void file_done(size_t file);
 private:
+    struct Held { uint32_t t; std::string acc, seq; };
+    struct Later { std::vector<Held> held; std::vector<uint16_t> count; bool done = false; };
+    void emit(uint32_t t, const char *acc, size_t acc_len, const char *seq, size_t seq_len);
     FILE *f_ = nullptr, *f2_ = nullptr;
     uint32_t save_target_ = 0;
     bool first12_enabled_ = true;
     std::vector<int64_t> seen_; // gcount as the reference sees it at that point of the file
+    size_t cur_file_ = 0;       // the file whose reads are written as they come
+    std::vector<Later> later_;  // [file]: what waits for its turn
 };
 
 } // namespace kidhost

@@ -224,11 +224,15 @@ int main(int argc, char **argv)
                     if (missing[f]) std::cout << "nark " << dname + prefix + e1 << std::endl;
                     std::cout << tct << " reads loaded" << std::endl;
                 } else {
-                    for (int mate = 0; mate < 2; mate++) {
-                        tct += run_file(eng, pf, fi++, saver);
+                    // the two mates are inflated, indexed and classified at the same time; "<tct> reads loaded" (:1030,:1036)
+                    // comes when a file is through, R1 first
+                    std::vector<long long> handed;
+                    run_files_together(eng, pf, fi, 2, saver, handed, [&](size_t mate) {
+                        tct += handed[mate];
                         if (t_first_file < 0) t_first_file = since_start();
                         std::cout << tct << " reads loaded" << std::endl;
-                    }
+                    });
+                    fi += 2;
                 }
             }
             finish_sample(eng, dname + prefix + "_result.txt");
