@@ -118,6 +118,17 @@ struct kid_sample {
     KidRareArgs *rare_fixed = nullptr;
     struct { uint32_t *out_final = nullptr; uint64_t read0 = 0; uint32_t fixed_len = 0; int32_t fixed_nk = 0; bool valid = false; } fixed_held;
     uint64_t dev_clock_batches = 0; // batches since kid_sample_kernel_time_device was last asked
+    // the hit log (kid_seenlog_* in kid_kernels.hip.h): where the resolver leaves the entry ordinals of its hits, and the
+    // scratch of the pass that turns them into bits of `seen`
+    uint32_t *seen_log = nullptr, *seen_log_tail = nullptr, *seen_sorted = nullptr, *log_counts = nullptr, *log_bin_total = nullptr;
+    uint32_t seen_log_cap = 0, log_nbins = 0;
+    unsigned long long *log_host_total = nullptr; // mapped host memory: entries of the last pass, written by the device
+    bool log_dirty = false;            // something may have been logged since the last pass
+    uint32_t launches_since_apply = 0;
+    uint64_t reads_since_apply = 0;
+    double log_entries_per_read = 4.0; // pace of the passes: a guess until the first pass has reported
+    uint64_t reads_of_last_pass = 0;
+    unsigned long long last_seen_host_total = 0;
     // very long records of host batches: their list and one word per k-mer position for the hits
     KidLongRec *long_recs = nullptr;
     uint64_t long_recs_cap = 0;
@@ -604,6 +615,12 @@ extern "C" void kid_sample_destroy(kid_sample *s)
     if (s->long_hits) hipFree(s->long_hits);
     if (s->long_tiles) hipFree(s->long_tiles);
     if (s->rare_fixed) hipFree(s->rare_fixed);
+    if (s->seen_log) hipFree(s->seen_log);
+    if (s->seen_log_tail) hipFree(s->seen_log_tail);
+    if (s->seen_sorted) hipFree(s->seen_sorted);
+    if (s->log_counts) hipFree(s->log_counts);
+    if (s->log_bin_total) hipFree(s->log_bin_total);
+    if (s->log_host_total) hipHostFree(s->log_host_total);
     if (s->order_ev) hipEventDestroy(s->order_ev);
     hipDeviceSynchronize();
     for (kid_sample::Slot &sl : s->slots) {
@@ -639,6 +656,10 @@ extern "C" int kid_sample_reset(kid_sample *s)
     }
     s->dev_clock_batches = 0;
     s->reads_submitted = 0;
+    if (s->seen_log_tail) KID_HIP(hipMemset(s->seen_log_tail, 0, KID_LOG_SHARDS * 64));
+    s->log_dirty = false;
+    s->launches_since_apply = 0;
+    s->reads_since_apply = 0;
     KID_HIP(hipMemset(s->seen, 0, s->seen_words * 4));
     KID_HIP(hipDeviceSynchronize());
     return KID_OK;
@@ -668,7 +689,24 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
     KID_S_HIP(hipMalloc(&s->seen, s->seen_words * 4));
     KID_S_HIP(hipStreamCreate(&s->stream));
     {
-        const KidRareArgs ra{s->gcount, s->stats, db->d.line_mask, 0u, 0ull, 0ull, 0, 0u, db->rows, s->seen, nullptr, nullptr};
+        // the hit log: for the minimizer-localised table (its resolver is the one that logs), bitmaps of up to 1024 pieces
+        const uint64_t nbins = (db->seen_bits + (1ull << KID_LOG_BIN_BITS) - 1) >> KID_LOG_BIN_BITS;
+        if (db->d.minloc && nbins <= 1024) {
+            uint64_t cap = db->info.n_entries / 4;                    // per region: the whole log holds 2 x the entries ...
+            cap = cap < 4096 ? 4096 : cap > (16u << 20) ? (16u << 20) : cap; // ... at most 128 M hits = 512 MiB (+ as much to sort them)
+            cap &= ~63ull;
+            s->seen_log_cap = (uint32_t)cap;
+            s->log_nbins = (uint32_t)nbins;
+            KID_S_HIP(hipMalloc(&s->seen_log, cap * KID_LOG_SHARDS * 4));
+            KID_S_HIP(hipMalloc(&s->seen_sorted, cap * KID_LOG_SHARDS * 4));
+            KID_S_HIP(hipMalloc(&s->seen_log_tail, KID_LOG_SHARDS * 64));
+            KID_S_HIP(hipMalloc(&s->log_counts, nbins * KID_LOG_WGS * 4));
+            KID_S_HIP(hipMalloc(&s->log_bin_total, nbins * 4));
+            KID_S_HIP(hipHostMalloc((void **)&s->log_host_total, 64, hipHostMallocMapped));
+            *s->log_host_total = 0;
+        }
+        const KidRareArgs ra{s->gcount, s->stats, db->d.line_mask, 0u, 0ull, 0ull, 0, 0u, db->rows, s->seen, nullptr, nullptr,
+                             s->seen_log, s->seen_log_tail, s->seen_log_cap, 0u};
         for (kid_sample::Scratch &sc : s->sets) {
             KID_S_HIP(hipMalloc(&sc.rare, sizeof(ra)));
             KID_S_HIP(hipMemcpy(sc.rare, &ra, sizeof(ra), hipMemcpyHostToDevice));
@@ -694,6 +732,58 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
 // prep_stream: where the prepare kernel runs.  The same as `stream` unless the read text is known to be ready earlier
 // than stream order says (host path: the copy stream behind the upload; kid_classify_batch_device under
 // KID_OPT_INPUTS_READY: an internal stream) -- then it overlaps with the classify kernels of the batch before.
+// The hit log -> bits of `seen` (kid_seenlog_* kernels), on `stream`, behind everything queued there.
+static int kid_seenlog_apply(kid_sample *s, hipStream_t stream)
+{
+    if (!s->seen_log || !s->log_dirty) return KID_OK;
+    void *dev_total = nullptr;
+    KID_HIP(hipHostGetDevicePointer(&dev_total, s->log_host_total, 0));
+    const KidLogArgs a{s->seen_log, s->seen_log_tail, s->seen_log_cap, s->log_nbins, s->log_counts, s->log_bin_total, s->seen_sorted,
+                       s->seen, s->seen_words, (unsigned long long *)dev_total};
+    const uint32_t nb = s->log_nbins;
+    hipLaunchKernelGGL(kid_seenlog_count_kernel, dim3(KID_LOG_WGS), dim3(256), nb * 4, stream, a);
+    hipLaunchKernelGGL(kid_seenlog_scan_kernel, dim3(nb), dim3(KID_LOG_WGS), 0, stream, a);
+    hipLaunchKernelGGL(kid_seenlog_scatter_kernel, dim3(KID_LOG_WGS), dim3(256), (4 * nb + 1 + KID_LOG_TILE) * 4, stream, a);
+    hipLaunchKernelGGL(kid_seenlog_apply_kernel, dim3(nb), dim3(1024), ((1u << (KID_LOG_BIN_BITS - 5)) + nb + 1) * 4, stream, a);
+    KID_HIP(hipMemsetAsync(s->seen_log_tail, 0, KID_LOG_SHARDS * 64, stream));
+    KID_HIP(hipGetLastError());
+    s->reads_of_last_pass = s->reads_since_apply;
+    s->log_dirty = false;
+    s->launches_since_apply = 0;
+    s->reads_since_apply = 0;
+    return KID_OK;
+}
+// ... when somebody wants to read the bitmap: behind everything the sample has queued anywhere (the caller synchronises after it)
+static int kid_seenlog_flush(kid_sample *s)
+{
+    if (!s->seen_log || !s->log_dirty) return KID_OK;
+    KID_HIP(hipDeviceSynchronize());
+    return kid_seenlog_apply(s, s->stream);
+}
+// before a launch of n_reads reads: run the pass if the log might not hold what the launch adds.  The device reports
+// the entries of every pass (mapped host memory, read without waiting: whatever pass has finished by now), from which
+// the hits per read of this sample are known; a region that does fill up falls back to atomics, so the pace only
+// matters for speed.
+static int kid_seenlog_pace(kid_sample *s, uint64_t n_reads, hipStream_t stream)
+{
+    if (!s->seen_log) return KID_OK;
+    const unsigned long long seen_total = *(volatile unsigned long long *)s->log_host_total;
+    if (seen_total != s->last_seen_host_total && s->reads_of_last_pass) {
+        s->last_seen_host_total = seen_total;
+        const double r = (double)seen_total / (double)s->reads_of_last_pass;
+        s->log_entries_per_read = r > 0.01 ? r * 1.25 : 0.0125;
+    }
+    const double room = 0.5 * (double)s->seen_log_cap * KID_LOG_SHARDS;
+    if (s->log_dirty && ((double)(s->reads_since_apply + n_reads) * s->log_entries_per_read > room || s->launches_since_apply >= 256)) {
+        int rc = kid_seenlog_apply(s, stream);
+        if (rc != KID_OK) return rc;
+    }
+    s->reads_since_apply += n_reads;
+    s->launches_since_apply++;
+    s->log_dirty = true;
+    return KID_OK;
+}
+
 // fastq: the batch is a block of FASTQ text with the host's line index (kid_classify_fastq_async); b.bases = the text,
 // b.start / b.stop = device arrays that RECEIVE what process_qual computes
 struct KidFastqIn {
@@ -717,6 +807,10 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
     }
     s->last_stream = stream;
     s->has_last_stream = true;
+    {
+        int rc = kid_seenlog_pace(s, b.n, stream);
+        if (rc != KID_OK) return rc;
+    }
     kid_sample::Scratch *scp = nullptr;
     KidRareArgs *rare = s->rare_fixed;
     if (!fixed) {
@@ -1410,6 +1504,8 @@ extern "C" int kid_sample_ucount_range(kid_sample *s, uint64_t slot_begin, uint6
         return kid_fail(KID_ERR_ARG, "bit range must be 128-aligned and inside the bitmap");
     int rc = kid_use_device(s->db->device);
     if (rc != KID_OK) return rc;
+    rc = kid_seenlog_flush(s);
+    if (rc != KID_OK) return rc;
     KID_HIP(hipDeviceSynchronize());
     const size_t nt = (size_t)s->db->info.ntar;
     KID_HIP(hipMemset(s->ucount, 0, nt * 8));
@@ -1453,6 +1549,9 @@ extern "C" int kid_sample_end_merged(kid_sample **samples, int n, int64_t *gcoun
             samples[i]->db->info.n_entries != samples[0]->db->info.n_entries)
             return kid_fail(KID_ERR_ARG, "samples[%d] belongs to a database built from other entries", i);
     }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++)
+            if (samples[i] == samples[j]) return kid_fail(KID_ERR_ARG, "samples[%d] and samples[%d] are the same sample (its reads would be counted twice)", j, i);
     kid_sample *s0 = samples[0];
     const size_t nt = (size_t)s0->db->info.ntar;
     int rc = kid_sample_gcount(s0, gcount);
@@ -1465,6 +1564,10 @@ extern "C" int kid_sample_end_merged(kid_sample **samples, int n, int64_t *gcoun
         const size_t nbytes = (size_t)s0->seen_words * 4;
         KID_HIP(tmp.alloc(nbytes));
         for (int i = 1; i < n; i++) {
+            rc = kid_use_device(samples[i]->db->device);
+            if (rc != KID_OK) return rc;
+            rc = kid_seenlog_flush(samples[i]); // its bitmap is read below
+            if (rc != KID_OK) return rc;
             rc = kid_sample_gcount(samples[i], g.data()); // (synchronises samples[i]'s device)
             if (rc != KID_OK) return rc;
             for (size_t t = 0; t < nt; t++) gcount[t] += g[t];
@@ -1503,6 +1606,8 @@ extern "C" int kid_sample_seen_export(kid_sample *s, uint64_t byte_off, uint64_t
     if (!s || (nbytes && !dst)) return kid_fail(KID_ERR_ARG, "null argument");
     if (byte_off + nbytes > s->seen_words * 4) return kid_fail(KID_ERR_ARG, "range outside the bitmap");
     int rc = kid_use_device(s->db->device);
+    if (rc != KID_OK) return rc;
+    rc = kid_seenlog_flush(s);
     if (rc != KID_OK) return rc;
     KID_HIP(hipDeviceSynchronize());
     KID_HIP(hipMemcpy(dst, (const uint8_t *)s->seen + byte_off, nbytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));

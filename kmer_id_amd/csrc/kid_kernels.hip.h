@@ -139,7 +139,17 @@ struct KidRareArgs {
     uint32_t *seen;
     uint32_t *out_final;   // of the current launch: written by kid_prepare_kernel / kid_rebase_kernel
     const void *desc;      // of the current launch (KidReadDesc *; null: fixed layout)
+    // the hit log (see kid_seenlog_*): the resolver appends the entry ordinals of its hits instead of setting their bits
+    // in `seen` with one memory-side atomic each; null: atomics
+    uint32_t *seen_log;      // KID_LOG_SHARDS regions of seen_log_cap entries
+    uint32_t *seen_log_tail; // their fill counters, 64 bytes apart
+    uint32_t seen_log_cap;
+    uint32_t pad2;
 };
+#define KID_LOG_SHARDS 8u       // one region per XCD (blockIdx & 7): ~5 k fetch-and-adds per launch and counter
+#define KID_LOG_NONE 0xFFFFFFFFu // a log place whose lookup turned out not to be a hit
+#define KID_LOG_BIN_BITS 18     // the apply pass owns the bitmap in pieces of 2^18 bits = 32 KiB of LDS
+#define KID_LOG_WGS 1024u       // workgroups of the counting / scattering kernels: 128 per region (a share = ~50 k entries)
 
 // ------------------------------------------------------------------ hash lookup
 // Hashtable::getHash, newkmer_10nx.cpp:204-233 (+ probe cap kmer_read_m3.cpp:232)
@@ -832,6 +842,10 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
         for (uint32_t base = 0; base < qn; base += 64u) {
             const uint32_t n = qn - base < 64u ? qn - base : 64u;
             const bool valid = lane < n;
+            // places in the hit log for this chunk: asked for now, looked at when the targets are known
+            uint32_t *const slog = rare->seen_log;
+            uint32_t log_at = 0;
+            if (slog && lane == 0) log_at = atomicAdd(rare->seen_log_tail + (blockIdx.x & (KID_LOG_SHARDS - 1u)) * 16u, n);
             uint32_t klo = 0, khi = 0, ln = 0, tag = 0;
             if (valid) { klo = CQ_klo[base + lane]; khi = CQ_khi[base + lane]; ln = CQ_lw[base + lane]; tag = CQ_tag[base + lane]; }
             const bool verified = (tag & 0x80u) != 0; // {target, entry ordinal} fetched when the header came in
@@ -887,6 +901,24 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
                 // last lane of a run issues the atomic.  60 hits per read: 121 M atomics per 2 M reads became 1/16 of
                 // that; each one occupies an L2 channel for ~16 cycles (profiles/r02/ab_hitlog.txt).
                 const bool sb = tgt > 1;
+                // The log: one coalesced store per chunk instead of one memory-side atomic per hit -- 2.5 M of those per
+                // 1 M read pairs, each worth several line fetches of channel time (8-10 % of the launch,
+                // profiles/r03/ab_noseen.txt).  kid_seenlog_* sets the bits later, a bitmap piece at a time in LDS.
+                bool logged = false;
+                if (slog) {
+                    const uint32_t cap = rare->seen_log_cap;
+                    const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)log_at);
+                    uint32_t *const at_p = slog + (size_t)(blockIdx.x & (KID_LOG_SHARDS - 1u)) * cap + at;
+                    if (at <= cap - n) { // (cap >= 64)
+                        if (valid) kid_store_u32_nowait(at_p + lane, sb ? slot : KID_LOG_NONE);
+                        logged = true;
+                    } else if (at < cap && lane < cap - at) {
+                        // the region is full: back to atomics until the log has been applied -- but the places that were
+                        // handed out up to its end must not be left as they are (the pass reads everything below the end)
+                        kid_store_u32_nowait(at_p + lane, KID_LOG_NONE);
+                    }
+                }
+                if (!logged) {
                 const uint32_t word = sb ? slot >> 5 : 0xFFFFFFF0u + (lane & 15u); // (no two neighbours without a hit alike)
                 uint32_t bits = sb ? 1u << (slot & 31u) : 0u;
 #define KID_SEEN_STEP(CTRL)                                                                                                    \
@@ -899,6 +931,7 @@ __global__ __launch_bounds__(512, KID_CLASSIFY_OCC) void kid_classify_kernel(con
 #undef KID_SEEN_STEP
                 const uint32_t w_next = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)word, 0x101, 0xF, 0xF, false); // row_shl:1
                 if (sb && w_next != word) kid_atomic_or_nowait(&rare->seen[word], bits);
+                }
             }
             const uint64_t hitm = __ballot(tgt > 0);
             if (hitm && lane == 0) atomicAdd(&WC[2], (uint32_t)__popcll(hitm));
@@ -1939,6 +1972,188 @@ __global__ __launch_bounds__(256) void kid_long_fold_kernel(const KidDevDb db, c
             atomicAdd(&gcount[0], ~0ull); // - 1
         }
         if (out_final) out_final[rc.read] = uf;
+    }
+}
+
+// ------------------------------------------------------------------ the hit log -> seen-bitmap
+// The classify kernels append the entry ordinals of their hits to KID_LOG_SHARDS log regions.  Setting 2.5 M random
+// bits of a 13.6 MB bitmap costs one memory-side atomic each however it is done from the classify kernel; here the
+// entries are first sorted by bitmap piece (a counting sort: count, scan, scatter), then ONE workgroup per piece sets
+// its bits in LDS and ORs the piece into the bitmap as its only writer.  Run every few dozen launches (and before
+// anybody reads the bitmap), over everything logged since: ~16 bytes of traffic per logged hit + one pass over the bitmap.
+struct KidLogArgs {
+    const uint32_t *log;
+    const uint32_t *tail;
+    uint32_t cap;
+    uint32_t nbins;        // pieces of 2^KID_LOG_BIN_BITS bits
+    uint32_t *counts;      // [bin][workgroup]: entries of the bin in the workgroup's share of the log
+    uint32_t *bin_total;   // [bin]
+    uint32_t *sorted;
+    uint32_t *seen;
+    uint64_t seen_words;
+    unsigned long long *host_total; // mapped host memory: entries of this pass (the host paces the passes by it)
+};
+// the share of the log a counting / scattering workgroup owns: region blockIdx / 128, 1/128 of its entries (whole
+// groups of 64 entries: a share starts on a 16-byte boundary)
+__device__ __forceinline__ void kid_log_share(const KidLogArgs &a, uint32_t &begin, uint32_t &end)
+{
+    const uint32_t per = KID_LOG_WGS / KID_LOG_SHARDS, sh = blockIdx.x / per, c = blockIdx.x % per;
+    const uint32_t t = a.tail[sh * 16u], filled = t < a.cap ? t : a.cap;
+    const uint32_t len = ((filled + per - 1u) / per + 63u) & ~63u;
+    begin = sh * a.cap + (c * len < filled ? c * len : filled);
+    end = sh * a.cap + ((c + 1u) * len < filled ? (c + 1u) * len : filled);
+}
+// every entry of [b0, b1) to f, four at a time (16-byte loads: these kernels are a stream over the log)
+template <class F>
+__device__ __forceinline__ void kid_log_for_each(const uint32_t *log, uint32_t b0, uint32_t b1, F &&f)
+{
+    const uint32_t n4 = (b1 - b0) >> 2;
+    const uint4 *p = reinterpret_cast<const uint4 *>(log + b0);
+    for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) {
+        const uint4 v = p[i];
+        if (v.x != KID_LOG_NONE) f(v.x);
+        if (v.y != KID_LOG_NONE) f(v.y);
+        if (v.z != KID_LOG_NONE) f(v.z);
+        if (v.w != KID_LOG_NONE) f(v.w);
+    }
+    for (uint32_t i = b0 + (n4 << 2) + threadIdx.x; i < b1; i += blockDim.x) {
+        const uint32_t e = log[i];
+        if (e != KID_LOG_NONE) f(e);
+    }
+}
+__global__ __launch_bounds__(256) void kid_seenlog_count_kernel(const KidLogArgs a)
+{
+    extern __shared__ uint32_t kid_lh[];
+    for (uint32_t i = threadIdx.x; i < a.nbins; i += blockDim.x) kid_lh[i] = 0;
+    __syncthreads();
+    uint32_t b0, b1;
+    kid_log_share(a, b0, b1);
+    kid_log_for_each(a.log, b0, b1, [&](const uint32_t e) { atomicAdd(&kid_lh[e >> KID_LOG_BIN_BITS], 1u); });
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < a.nbins; i += blockDim.x) a.counts[i * KID_LOG_WGS + blockIdx.x] = kid_lh[i];
+}
+// per bin: exclusive scan of the workgroups' counts (in place) and the bin's total
+__global__ __launch_bounds__(1024) void kid_seenlog_scan_kernel(const KidLogArgs a)
+{
+    __shared__ uint32_t part[KID_LOG_WGS];
+    uint32_t *c = a.counts + (size_t)blockIdx.x * KID_LOG_WGS;
+    const uint32_t v = c[threadIdx.x];
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t o = 1; o < KID_LOG_WGS; o <<= 1) {
+        const uint32_t add = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    c[threadIdx.x] = part[threadIdx.x] - v;
+    if (threadIdx.x == KID_LOG_WGS - 1u) a.bin_total[blockIdx.x] = part[threadIdx.x];
+}
+// where the bins start in `sorted`: exclusive scan of bin_total (<= 1024 bins) into LDS; returns the grand total
+__device__ __forceinline__ uint32_t kid_log_bin_bases(const KidLogArgs &a, uint32_t *bases /* nbins + 1 */)
+{
+    // (one wave does it: the totals are few)
+    if (threadIdx.x < 64u) {
+        uint32_t run = 0;
+        for (uint32_t i0 = 0; i0 < a.nbins; i0 += 64u) {
+            const uint32_t i = i0 + threadIdx.x;
+            uint32_t v = i < a.nbins ? a.bin_total[i] : 0u, x = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, o); if ((int)threadIdx.x >= o) x += y; }
+            if (i < a.nbins) bases[i] = run + x - v;
+            run += (uint32_t)__shfl((int)x, 63);
+        }
+        if (threadIdx.x == 0) bases[a.nbins] = run;
+    }
+    __syncthreads();
+    return bases[a.nbins];
+}
+// exclusive scan of v[0 .. n) (n <= 4 x blockDim) into out[0 .. n), by a workgroup of 256 threads; returns the total
+__device__ __forceinline__ uint32_t kid_block_exscan(const uint32_t *v, uint32_t *out, const uint32_t n, uint32_t *wave_tot /* [5] */)
+{
+    const uint32_t t = threadIdx.x, i0 = 4u * t;
+    uint32_t x[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { x[j] = i0 + j < n ? v[i0 + j] : 0u; sum += x[j]; }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, o); if ((int)(t & 63u) >= o) inc += y; }
+    if ((t & 63u) == 63u) wave_tot[t >> 6] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < (t >> 6); w++) before += wave_tot[w];
+    uint32_t run = before + inc - sum;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { if (i0 + j < n) out[i0 + j] = run; run += x[j]; }
+    const uint32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+    return total;
+}
+// The log -> `sorted`, bin by bin.  A workgroup takes its share in tiles of KID_LOG_TILE entries and sorts a tile in LDS
+// first (count, scan, place), so that what goes out to memory are runs of neighbouring entries of one bin -- scattering
+// the entries one by one took 7 ps each (47 M partial-line writes per pass, profiles/r03/seen_log_first_kernel_stats.csv).
+#define KID_LOG_TILE 4096u
+__global__ __launch_bounds__(256) void kid_seenlog_scatter_kernel(const KidLogArgs a)
+{
+    extern __shared__ uint32_t kid_lh[]; // bin bases [nbins + 1], next place of this workgroup per bin [nbins], the tile's counts and offsets [2 nbins], the tile
+    const uint32_t nb = a.nbins;
+    uint32_t *bases = kid_lh, *next = bases + nb + 1u, *hist = next + nb, *toff = hist + nb, *stage = toff + nb;
+    __shared__ uint32_t wave_tot[5];
+    const uint32_t total = kid_log_bin_bases(a, bases);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.host_total) *a.host_total = total;
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) next[i] = bases[i] + a.counts[i * KID_LOG_WGS + blockIdx.x];
+    uint32_t b0, b1;
+    kid_log_share(a, b0, b1);
+    for (uint32_t t0 = b0; t0 < b1; t0 += KID_LOG_TILE) { // (workgroup-uniform)
+        const uint32_t n = b1 - t0 < KID_LOG_TILE ? b1 - t0 : KID_LOG_TILE;
+        for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        uint32_t e[KID_LOG_TILE / 256u], r[KID_LOG_TILE / 256u];
+#pragma unroll
+        for (uint32_t j = 0; j < KID_LOG_TILE / 256u; j++) {
+            const uint32_t i = j * 256u + threadIdx.x;
+            e[j] = i < n ? a.log[t0 + i] : KID_LOG_NONE;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < KID_LOG_TILE / 256u; j++)
+            r[j] = e[j] != KID_LOG_NONE ? atomicAdd(&hist[e[j] >> KID_LOG_BIN_BITS], 1u) : 0u; // its rank among the tile's entries of its bin
+        __syncthreads();
+        const uint32_t tile_n = kid_block_exscan(hist, toff, nb, wave_tot);
+#pragma unroll
+        for (uint32_t j = 0; j < KID_LOG_TILE / 256u; j++)
+            if (e[j] != KID_LOG_NONE) stage[toff[e[j] >> KID_LOG_BIN_BITS] + r[j]] = e[j];
+        __syncthreads();
+        for (uint32_t p = threadIdx.x; p < tile_n; p += blockDim.x) { // neighbours in `stage` are neighbours in `sorted`
+            const uint32_t v = stage[p], bin = v >> KID_LOG_BIN_BITS;
+            a.sorted[next[bin] + (p - toff[bin])] = v;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) next[i] += hist[i];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void kid_seenlog_apply_kernel(const KidLogArgs a)
+{
+    extern __shared__ uint32_t kid_lh[]; // 2^KID_LOG_BIN_BITS bits of the bitmap, then the bin bases
+    const uint32_t piece_words = 1u << (KID_LOG_BIN_BITS - 5);
+    uint32_t *piece = kid_lh, *bases = kid_lh + piece_words;
+    kid_log_bin_bases(a, bases);
+    const uint32_t e0 = bases[blockIdx.x], e1 = bases[blockIdx.x + 1u];
+    if (e0 == e1) return; // (workgroup-uniform)
+    for (uint32_t i = threadIdx.x; i < piece_words; i += blockDim.x) piece[i] = 0;
+    __syncthreads();
+    auto set = [&](const uint32_t v) { const uint32_t e = v & ((1u << KID_LOG_BIN_BITS) - 1u); atomicOr(&piece[e >> 5], 1u << (e & 31u)); };
+    // the bin's entries, 16 bytes per load between the first and the last 16-byte boundary
+    const uint32_t up = (e0 + 3u) & ~3u, a0 = up < e1 ? up : e1, a1 = a0 + ((e1 - a0) & ~3u);
+    for (uint32_t i = e0 + threadIdx.x; i < a0; i += blockDim.x) set(a.sorted[i]);
+    const uint4 *p4 = reinterpret_cast<const uint4 *>(a.sorted + a0);
+    for (uint32_t i = threadIdx.x; i < (a1 - a0) >> 2; i += blockDim.x) { const uint4 v = p4[i]; set(v.x); set(v.y); set(v.z); set(v.w); }
+    for (uint32_t i = a1 + threadIdx.x; i < e1; i += blockDim.x) set(a.sorted[i]);
+    __syncthreads();
+    const uint64_t w0 = (uint64_t)blockIdx.x * piece_words;
+    for (uint32_t i = threadIdx.x; i < piece_words; i += blockDim.x) {
+        const uint32_t v = piece[i];
+        if (v && w0 + i < a.seen_words) a.seen[w0 + i] |= v; // the only writer of this piece while the pass runs
     }
 }
 

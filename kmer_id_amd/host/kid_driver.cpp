@@ -117,7 +117,9 @@ struct Prefetcher::Impl {
         std::deque<std::unique_ptr<ReadBatch>> q;
         bool done = false, failed = false;
         Fatal failure{0, ""};
+        SourceStats stats;
     };
+    double waited_s = 0;
     std::vector<SourceOpener> files;
     std::vector<Slot> slots;
     std::vector<std::thread> pool;
@@ -148,6 +150,9 @@ struct Prefetcher::Impl {
                         cv.notify_all();
                     }
                     src->close();
+                    const SourceStats st = src->stats();
+                    std::lock_guard<std::mutex> lk(m);
+                    slots[i].stats = st;
                 }
             } catch (const Fatal &f) {
                 std::lock_guard<std::mutex> lk(m);
@@ -184,11 +189,21 @@ Prefetcher::~Prefetcher()
     for (std::thread &t : impl_->pool) t.join();
 }
 
+SourceStats Prefetcher::file_stats(size_t index)
+{
+    std::lock_guard<std::mutex> lk(impl_->m);
+    return impl_->slots[index].stats;
+}
+
+double Prefetcher::seconds_waited() const { return impl_->waited_s; }
+
 std::unique_ptr<ReadBatch> Prefetcher::next(size_t index)
 {
     Impl::Slot &s = impl_->slots[index];
     std::unique_lock<std::mutex> lk(impl_->m);
+    const auto t0 = std::chrono::steady_clock::now();
     impl_->cv.wait(lk, [&] { return !s.q.empty() || s.done; });
+    impl_->waited_s += seconds_since(t0);
     if (!s.q.empty()) {
         std::unique_ptr<ReadBatch> b = std::move(s.q.front());
         s.q.pop_front();
@@ -222,7 +237,9 @@ std::unique_ptr<ReadBatch> Prefetcher::next_any(size_t lo, size_t hi, size_t &wh
             if (s.failed) { which = i; throw s.failure; }
         }
         if (all_done) return nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         impl_->cv.wait(lk);
+        impl_->waited_s += seconds_since(t0);
     }
 }
 
@@ -252,7 +269,9 @@ void run_files_together(Engine &e, Prefetcher &pf, size_t first, size_t count, R
     };
     auto retire = [&]() {
         InFlight &f = q.front();
+        const auto t0 = std::chrono::steady_clock::now();
         int rc = kid_classify_wait(f.sample, f.ticket);
+        e.gpu_wait_s += seconds_since(t0);
         if (rc != KID_OK) die_kid(rc);
         handed[f.file] += saver.add_batch_of(f.file, *f.batch, f.final_targ, e.k);
         pending[f.file]--;
@@ -274,6 +293,7 @@ void run_files_together(Engine &e, Prefetcher &pf, size_t first, size_t count, R
             f.sample = e.samples[e.next_sample]; // batches are dealt round-robin over the devices
             e.next_sample = (e.next_sample + 1) % e.samples.size();
             int rc;
+            const auto t_sub = std::chrono::steady_clock::now();
             if (f.batch->fq) {
                 FastqBlock &fb = *f.batch->fq;
                 f.batch->start.resize(nr);
@@ -284,6 +304,7 @@ void run_files_together(Engine &e, Prefetcher &pf, size_t first, size_t count, R
                 rc = kid_classify_batch_async(f.sample, f.batch->bases.data(), f.batch->offsets.data(), f.batch->start.data(),
                                               f.batch->stop.data(), nr, f.final_targ.data(), &f.ticket);
             }
+            e.submit_s += seconds_since(t_sub);
             if (rc != KID_OK) die_kid(rc);
             while (q.size() > max_in_flight) retire();
         }
@@ -315,7 +336,9 @@ long long run_file(Engine &e, Prefetcher &pf, size_t index, ReadSaver &saver)
     const size_t max_in_flight = 2 * e.samples.size();
     auto retire = [&]() {
         InFlight &f = q.front();
+        const auto t0 = std::chrono::steady_clock::now();
         int rc = kid_classify_wait(f.sample, f.ticket);
+        e.gpu_wait_s += seconds_since(t0);
         if (rc != KID_OK) die_kid(rc);
         n += saver.add_batch(*f.batch, f.final_targ, e.k);
         q.pop_front();
@@ -330,6 +353,7 @@ long long run_file(Engine &e, Prefetcher &pf, size_t index, ReadSaver &saver)
             f.sample = e.samples[e.next_sample]; // batches are dealt round-robin over the devices
             e.next_sample = (e.next_sample + 1) % e.samples.size();
             int rc;
+            const auto t_sub = std::chrono::steady_clock::now();
             if (f.batch->fq) {
                 FastqBlock &fb = *f.batch->fq;
                 f.batch->start.resize(nr);
@@ -340,6 +364,7 @@ long long run_file(Engine &e, Prefetcher &pf, size_t index, ReadSaver &saver)
                 rc = kid_classify_batch_async(f.sample, f.batch->bases.data(), f.batch->offsets.data(), f.batch->start.data(),
                                               f.batch->stop.data(), nr, f.final_targ.data(), &f.ticket);
             }
+            e.submit_s += seconds_since(t_sub);
             if (rc != KID_OK) die_kid(rc);
             while (q.size() > max_in_flight) retire();
         }

@@ -24,6 +24,7 @@ struct Engine {
     int ntar = 0, k = 30;
     size_t batch_reads = 1 << 20;
     size_t batch_bases = 256u << 20;
+    double gpu_wait_s = 0, submit_s = 0; // the consumer, inside kid_classify_wait / kid_classify_*_async (--timing)
     ~Engine();
 };
 
@@ -65,6 +66,8 @@ public:
     // are at their end.  A file that failed throws its Fatal only once the files before it in the range are through
     // (the reference would have read those completely before it met the failure).
     std::unique_ptr<ReadBatch> next_any(size_t lo, size_t hi, size_t &which);
+    SourceStats file_stats(size_t index); // of a file that is through
+    double seconds_waited() const;        // the consumer, inside next() / next_any(): the host stages were the slower side
 private:
     struct Impl;
     std::unique_ptr<Impl> impl_;

@@ -138,11 +138,17 @@ struct ReadBatch {
 
 // A file of reads delivered as batches.  fill() clears `out`, appends reads until max_reads reads or
 // max_bases bases are in it, and returns false when the file is exhausted and nothing was appended.
+struct SourceStats { // seconds a file's host stages took (--timing)
+    double inflate_s = 0; // inside gzread (its own thread)
+    double index_s = 0;   // finding lines / parsing / trimming (the reader thread)
+    uint64_t text_bytes = 0;
+};
 class ReadSource {
 public:
     virtual ~ReadSource() {}
     virtual bool fill(ReadBatch &out, size_t max_reads, size_t max_bases) = 0;
     virtual void close() {}
+    virtual SourceStats stats() const { return SourceStats(); }
 };
 
 // process_fqgz (newkmer_10nx.cpp:762-816): FASTQ(.gz).  One thread inflates (GzLineBlocks), fill() finds the lines of
@@ -155,8 +161,7 @@ public:
     FastqStream(const std::string &path, int k, size_t block_bytes = (size_t)8 << 20);
     bool fill(ReadBatch &out, size_t max_reads, size_t max_bases = (size_t)-1) override;
     void close() override { in_.close(); }
-    double inflate_seconds() const { return in_.inflate_seconds(); }
-    double index_seconds() const { return index_s_; }
+    SourceStats stats() const override { SourceStats s; s.inflate_s = in_.inflate_seconds(); s.index_s = index_s_; s.text_bytes = in_.bytes_out(); return s; }
 private:
     GzLineBlocks in_;
     int k_;

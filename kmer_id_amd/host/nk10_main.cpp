@@ -101,15 +101,19 @@ int main(int argc, char **argv)
         const double t_db_loaded = since_start();
         double t_gpu_ready = -1, t_first_file = -1;
         size_t n_entries = ps.keys.size(), n_devices = 0;
+        std::string files_json; // per read file: seconds of its host stages
+        double host_wait_s = 0, gpu_wait_s = 0, submit_s = 0;
         auto print_timing = [&]() {
             if (!timing) return;
             fprintf(stderr, "{\"nk10_timing\": {\"entries\": %zu, \"from_cache\": %s, \"probes_text_bytes\": %llu, \"probes_inflate_s\": %.3f, "
                             "\"probes_parse_wall_s\": %.3f, \"parse_threads\": %d, \"cache_read_s\": %.3f, \"cache_write_s\": %.3f, "
                             "\"db_loaded_at_s\": %.3f, \"gpu_upload_and_build_s\": %.3f, \"gpu_ready_at_s\": %.3f, "
-                            "\"first_file_classified_at_s\": %.3f, \"total_s\": %.3f, \"log2_slots\": %d, \"devices\": %zu}}\n",
+                            "\"first_file_classified_at_s\": %.3f, \"total_s\": %.3f, \"log2_slots\": %d, \"devices\": %zu, "
+                            "\"consumer_waited_for_host_stages_s\": %.3f, \"consumer_waited_for_gpu_s\": %.3f, \"consumer_submit_s\": %.3f, "
+                            "\"reader_threads\": %d, \"files\": [%s]}}\n",
                     n_entries, from_cache ? "true" : "false", (unsigned long long)tm.text_bytes, tm.inflate_s, tm.parse_wall_s,
                     tm.parse_threads, tm.cache_read_s, tm.cache_write_s, t_db_loaded, tm.gpu_build_s, t_gpu_ready, t_first_file,
-                    since_start(), log2_slots, n_devices);
+                    since_start(), log2_slots, n_devices, host_wait_s, gpu_wait_s, submit_s, threads, files_json.c_str());
         };
         std::cout << "tree loaded" << std::endl;
         std::cout << ps.lines_parsed << " kmers loaded" << std::endl;
@@ -236,6 +240,18 @@ int main(int argc, char **argv)
                 }
             }
             finish_sample(eng, dname + prefix + "_result.txt");
+        }
+        if (timing) {
+            for (size_t i = 0; i < fi; i++) {
+                const SourceStats st = pf.file_stats(i);
+                char buf[256];
+                snprintf(buf, sizeof(buf), "%s{\"file\": %zu, \"text_bytes\": %llu, \"inflate_s\": %.3f, \"index_s\": %.3f}", i ? ", " : "", i,
+                         (unsigned long long)st.text_bytes, st.inflate_s, st.index_s);
+                files_json += buf;
+            }
+            host_wait_s = pf.seconds_waited();
+            gpu_wait_s = eng.gpu_wait_s;
+            submit_s = eng.submit_s;
         }
         print_timing();
     } catch (const Fatal &f) {

@@ -32,15 +32,4 @@ for name, frac in (("no hits", 0.0), ("25 % of the reads from the genomes", 0.25
     ms, launches = s.kernel_time()
     st = s.stats()
     print("%-40s %.3f ms per 2 M reads, %.1f G lookups/s, hits per read %.1f, cells per lookup %.3f" % (name, ms / launches, st["lookups"] / 6 / (ms / launches) / 1e6, st["hits"] / st["reads"], st["probes"] / st["lookups"]))
-    if os.environ.get("PAIRS") == "1":  # -DKID_PROFILE build: where the cycles of a wave went
-        import ctypes
-        import kmer_id_amd
-        lib = kmer_id_amd.load()
-        out = (ctypes.c_uint64 * 24)()
-        lib.kid_sample_debug_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
-        lib.kid_sample_debug_counters.restype = ctypes.c_int
-        if lib.kid_sample_debug_counters(s._h, out) == 0:
-            v = list(out)[:10]
-            names = ["wait words A", "front A", "wait words B", "front B", "wait headers A", "back A", "wait headers B", "back B", "tail", "(resolver)"]
-            print("   " + ", ".join("%s %.0f" % (nm, x / (6 * n)) for nm, x in zip(names, v)) + "  ticks/read")
     s.close()

@@ -10,21 +10,38 @@ import sys
 
 root = sys.argv[1]
 out = {"source": root}
+# what the profile is tied to (bench.py refuses a profile of other kernel sources)
+import hashlib
+_repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_h = hashlib.sha256()
+for _rel in ("kmer_id_amd/csrc/kid_kernels.hip.h", "kmer_id_amd/csrc/kid_api.hip", "kmer_id_amd/csrc/kid_common.h"):
+    _h.update(open(os.path.join(_repo, _rel), "rb").read())
+out["kernel_source_sha256_16"] = _h.hexdigest()[:16]
+out["commit"] = os.environ.get("KID_COMMIT")  # (the GPU box has no .git: tools/pmc_traffic.sh is given the commit)
 for d in sorted(os.listdir(root)):
     p = os.path.join(root, d)
     if not os.path.isdir(p):
         continue
     # two classify kernels run per batch (pair loop / general loops) and one of them returns at once:
     # the numbers are those of the kernel that did the work (largest values), the other is only named
+    # rocprofv3 writes one CSV per PROCESS it saw: the one with the most classify dispatches is the bench process (a
+    # stray child -- the nk10 leg -- would otherwise overwrite its numbers)
+    best = None
     for f in glob.glob(p + "/**/*_counter_collection.csv", recursive=True):
         per = collections.defaultdict(lambda: collections.defaultdict(list))
         meta = {}
+        n_rows = 0
         for r in csv.DictReader(open(f)):
             if "classify" in r["Kernel_Name"]:
                 per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 meta[r["Kernel_Name"]] = r
-        if not per:
-            continue
+                n_rows += 1
+        if per and (best is None or n_rows > best[0]):
+            best = (n_rows, per, meta)
+    if best:
+        _, per, meta = best
+        # several classify kernels may run per batch and all but one return at once: the numbers are those of the
+        # kernel that did the work (largest values)
         name = max(per, key=lambda k: sum(sum(v) for v in per[k].values()))
         r = meta[name]
         out.setdefault("kernel", name)
