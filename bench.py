@@ -179,56 +179,77 @@ def host_buffer_leg(db, device, batches, n_reads, steps):
 
 
 def cli_e2e_leg(threads):
-    """nk10 (the reference's command line) on a directory of FASTQ.gz pairs: files in -> _result.txt/_reads.txt out.
-    Host-bound (gzip inflate + parsing); a small DB scale so that the text DB load is not what is measured."""
+    """nk10 (the reference's command line) on directories of FASTQ.gz pairs: files in -> _result.txt/_reads.txt out, one
+    sample and two samples of 1 M pairs each.  Host-bound: zlib inflates a stream at ~0.4 GB/s of text, everything behind
+    it (finding the lines; trimming and classification on the GPU) is faster.  A small DB scale, so that the text DB load
+    is not what is measured; the files come from tools/kid_synth_files.cpp."""
     import subprocess
     import tempfile
     from kmer_id_amd import _build
     nk10 = _build.cli_path("nk10")
-    if not os.path.exists(nk10):
+    tool = _build.cli_path("kid_synth_files")
+    if not os.path.exists(nk10) or not os.path.exists(tool):
         return None
-    S, P = 2, 100_000
+    P = 1_000_000
     cwd = tempfile.mkdtemp(prefix="kid_e2e_")
     try:
         parent, cnt = synth.load_taxonomy("bact10")
-        cum = synth.cumulative(synth.scaled_counts(cnt, 1e-3))
-        keys, targets = synth.db_keys(cum, K)
         os.makedirs(os.path.join(cwd, "bact10"))
-        with open(os.path.join(cwd, "bact10", "btree_10.txt"), "w") as fh:
-            for y, x in enumerate(parent.tolist()):
-                if y >= 2 and x != 1:
-                    fh.write("%d\t%d\n" % (x, y))
+        with open(os.path.join(cwd, "counts.txt"), "w") as fh:
+            fh.write("".join("%d,%d\n" % (t, c) for t, c in enumerate(cnt.tolist())))
+        tree = os.path.join(cwd, "bact10", "btree_10.txt")
+        with open(tree, "w") as fh:
+            fh.write("".join("%d\t%d\n" % (x, y) for y, x in enumerate(parent.tolist()) if y >= 2 and x != 1))
         open(os.path.join(cwd, "bact10", "bData10.txt"), "w").write("4\tX\n")
-        synth.write_probes_gz(os.path.join(cwd, "bact10", "probes10.txt.gz"), keys, targets, K)
-        fq, empty = os.path.join(cwd, "fq") + "/", os.path.join(cwd, "empty") + "/"
-        os.makedirs(fq); os.makedirs(empty)
-        for s_ in range(S):
-            for mate in (1, 2):
-                r0 = (2 * s_ + mate - 1) * P
-                synth.write_fastq_gz(fq + "S%d_R%d_tr.fastq.gz" % (s_, mate), synth.reads(cum, parent, P, 150, K, r0=r0),
-                                     synth.qualities(P, 150, r0=r0), 150, mate=mate)
+        counts = os.path.join(cwd, "counts.txt")
+        subprocess.check_call([tool, "probes", "--counts", counts, "--scale", "1e-3", "--out", os.path.join(cwd, "bact10", "probes10.txt.gz")],
+                              stderr=subprocess.DEVNULL)
+        dirs = {}
+        for name, S in (("one_sample", 1), ("two_samples", 2)):
+            d = os.path.join(cwd, name) + "/"
+            os.makedirs(d)
+            subprocess.check_call([tool, "fastq", "--counts", counts, "--tree", tree, "--scale", "1e-3", "--out-dir", d, "--samples", str(S),
+                                   "--pairs", str(P)], stderr=subprocess.DEVNULL)
+            dirs[name] = (d, S)
+        empty = os.path.join(cwd, "empty") + "/"
+        os.makedirs(empty)
         cache = os.path.join(cwd, "db.kidx")
 
         def run(d):
             t = time.perf_counter()
-            subprocess.run([nk10, d, "--log2-slots", "22", "--db-cache", cache, "--threads", str(threads)], cwd=cwd, check=True,
-                           stdout=subprocess.DEVNULL)
-            return time.perf_counter() - t
+            r = subprocess.run([nk10, d, "--log2-slots", "22", "--db-cache", cache, "--threads", str(threads), "--timing"], cwd=cwd,
+                               check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            tm = [json.loads(l)["nk10_timing"] for l in r.stderr.decode("latin-1").splitlines() if l.startswith('{"nk10_timing"')]
+            return time.perf_counter() - t, (tm[0] if tm else None)
         run(empty)
-        base = min(run(empty) for _ in range(2))
-        wall = run(fq)
-        g = sum(int(line.split(",")[1]) for line in open(fq + "S0_result.txt"))
-        return {"pairs_per_s": S * P / max(wall - base, 1e-6), "wall_s": wall, "startup_s": base, "samples": S, "pairs_per_sample": P,
-                "reader_threads": threads, "reads_counted_sample0": g,
-                "what": "nk10 <dir> on %d samples x %d pairs of 150 bp FASTQ.gz (mixed qualities, trimmed by process_qual), wall minus "
-                        "the program's startup on an empty directory; bounded by gzip inflate + parsing on the host" % (S, P)}
+        base = min(run(empty)[0] for _ in range(2))
+        out = {"startup_s": base, "reader_threads": threads, "pairs_per_sample": P,
+               "what": "nk10 <dir> on 1 and on 2 samples x %d pairs of 150 bp FASTQ.gz (mixed qualities; process_qual and "
+                       "classification on the GPU), wall minus the program's startup on an empty directory; bounded by zlib "
+                       "inflate: one stream per file, the two mates of a sample at the same time" % P}
+        for name, (d, S) in dirs.items():
+            wall, tm = run(d)
+            g = sum(int(line.split(",")[1]) for line in open(d + "S0_result.txt"))
+            out[name] = {"pairs_per_s": S * P / max(wall - base, 1e-6), "wall_s": wall, "reads_counted_sample0": g,
+                         "stages": None if tm is None else {k_: tm[k_] for k_ in ("consumer_waited_for_host_stages_s", "consumer_waited_for_gpu_s",
+                                                                                  "consumer_submit_s", "files") if k_ in tm}}
+        out["pairs_per_s"] = out["two_samples"]["pairs_per_s"]
+        return out
     finally:
         import shutil
         shutil.rmtree(cwd, ignore_errors=True)
 
 
-PMC_PROFILES = {"1m": ["profiles/r02/pmc_final.json", "profiles/r01/pmc_final.json"],
-                "roofline100m": ["profiles/r02/pmc_100m.json"]}
+def kernel_source_sha():
+    """what a counter profile is tied to: the text of the kernels it was taken on"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("kmer_id_amd/csrc/kid_kernels.hip.h", "kmer_id_amd/csrc/kid_api.hip", "kmer_id_amd/csrc/kid_common.h"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()[:16]
+
+
+PMC_PROFILES = {"1m": ["profiles/r03/pmc_final.json"], "roofline100m": ["profiles/r03/pmc_100m.json"]}
 
 
 def traffic_from_profile(args, info):
@@ -239,18 +260,27 @@ def traffic_from_profile(args, info):
     if (args.scale != 1.0 or args.pairs != CONFIGS[args.config]["pairs"] or args.log2_slots != 30 or
             args.geometry != "minloc" or args.read_len != 150):
         return None, "none: not the profiled workload"
+    sha = kernel_source_sha()
+    why = "none: no committed counter profile for this workload"
     for rel in PMC_PROFILES.get(args.config, []):
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
             continue
         try:
             d = json.load(open(path))
+            # a profile of other kernels says nothing about these: the summary carries the hash of the sources it was taken on
+            if d.get("kernel_source_sha256_16") != sha:
+                why = "none: %s was taken on other kernel sources (%s, these are %s): rerun tools/pmc_traffic.sh" % (
+                    rel, d.get("kernel_source_sha256_16"), sha)
+                continue
             rd = d["TCC_EA0_RDREQ_128B_sum"]["avg"] * 128 + d["TCC_EA0_RDREQ_64B_sum"]["avg"] * 64 + d["TCC_EA0_RDREQ_32B_sum"]["avg"] * 32
-            return rd + d["WRITE_SIZE"]["avg"] * 1024, ("committed counter profile %s (rocprofv3 --pmc passes of this command on an "
-                                                        "earlier run; not collected live)" % rel)
-        except Exception:
+            return rd + d["WRITE_SIZE"]["avg"] * 1024, ("committed counter profile %s (rocprofv3 --pmc passes of this command; kernel sources "
+                                                        "%s = the running ones, commit %s, kernel %s; not collected live)" % (
+                                                            rel, sha, d.get("commit"), (d.get("kernel") or "")[:60]))
+        except Exception as e:
+            why = "none: %s unreadable (%r)" % (rel, e)
             continue
-    return None, "none: no committed counter profile for this workload"
+    return None, why
 
 
 def main():
@@ -352,12 +382,15 @@ def main():
         ev[i][0].record(stream)
         step(i)
         ev[i][1].record(stream)
+    t_queued = time.perf_counter()
     # close the sample: ucount from the seen-bitmap (+ RCCL merge over the ranks)
+    merge_timing = {}
     if world > 1:
-        g, u = merge_sample(sample, device if args.backend == "nccl" else torch.device("cpu"))
+        g, u = merge_sample(sample, device if args.backend == "nccl" else torch.device("cpu"), timing=merge_timing)
     else:
         g, u = sample.end()
     torch.cuda.synchronize(device)
+    t_closed = time.perf_counter()
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
@@ -402,6 +435,15 @@ def main():
         torch.cuda.empty_cache()
         if not xcheck:
             raise SystemExit("minimizer-localised and reference geometries disagree")
+    # N > 1: where the time of every rank went (so that a scaling record shows WHERE scaling is lost): its own steps,
+    # closing its sample + the merge phases, waiting for the slowest rank
+    per_rank = None
+    if world > 1:
+        mine = {"rank": rank, "steps_gpu_ms": sum(kernel_ms), "classify_kernel_ms": classify_ms, "queued_after_s": t_queued - t0,
+                "closed_after_s": t_closed - t0, "barrier_wait_s": t1 - t_closed, **{k_: round(v_, 6) for k_, v_ in merge_timing.items()}}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
     kern_s = sum(kernel_ms) / 1e3
     # algorithmic bytes: 16 B per table cell the REFERENCE's table geometry reads for
     # these lookups (counted exactly on the reference-geometry table above), whatever our own
@@ -413,7 +455,12 @@ def main():
         probes_per_launch = cells_read_per_launch
     avg_step_gpu_s = kern_s / args.steps
     avg_kernel_s = classify_ms / 1e3 / args.steps
-    achieved = probes_per_launch * 16 / avg_kernel_s / 1e9
+    # ... + the read text: since round 3 the classify kernel reads the ASCII bases itself (there is no pack kernel in front
+    # of it any more), one byte per base of every read, like the reference's loop does (newkmer_10nx.cpp:475-477)
+    table_bytes_per_launch = probes_per_launch * 16
+    text_bytes_per_launch = float(n_reads) * READ_LEN
+    algorithmic_bytes = table_bytes_per_launch + text_bytes_per_launch
+    achieved = algorithmic_bytes / avg_kernel_s / 1e9
 
     extra = {}
     if args.gather and rank == 0:
@@ -490,16 +537,20 @@ def main():
                                    "%d synthetic %d bp read pairs per GPU per step, reads resident in HBM" % (
                                        info.n_entries, args.log2_slots, args.pairs, READ_LEN),
                        "name": args.config, "inputs_ready_option": bool(args.overlap_pack), "db_scale": args.scale, "pairs_per_gpu_per_step": args.pairs, "read_len": READ_LEN, "k": K,
-                       "merged_counters_equal_single_table": ranks_verified,
+                       "merged_counters_equal_single_table": ranks_verified, "per_rank": per_rank,
+                       "slowest_rank": None if per_rank is None else max(per_rank, key=lambda r_: r_["closed_after_s"])["rank"],
                        "sharding": "reads sharded over %d rank(s), DB replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "kid_classify_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "avg_kernel_ms_device_clock": (dev_ms / dev_launches) if dev_launches else None,
-                         "kernel_time_source": "HIP events on the launch stream around the batch's kid_classify_kernel launches "
-                                               "(the kernel that does the work + its twin that returns at once, ~4 us)",
+                         "kernel_time_source": "HIP events on the launch stream around the batch's kid_classify_kernel launch (a "
+                                               "fixed-layout batch is ONE kernel: it reads the ASCII text, no pack / prepare kernels)",
                          "avg_step_gpu_ms": avg_step_gpu_s * 1e3,
-                         "algorithmic_bytes_per_launch": probes_per_launch * 16,
+                         "algorithmic_bytes_per_launch": algorithmic_bytes,
+                         "algorithmic_table_bytes_per_launch": table_bytes_per_launch, "algorithmic_text_bytes_per_launch": text_bytes_per_launch,
+                         "frac_table_bytes_only": table_bytes_per_launch / avg_kernel_s / 1e9 / HBM_PEAK_GBPS,
+                         "kernel_source_sha256_16": kernel_source_sha(),
                          "lookups_per_launch": st["lookups"] / args.steps, "probes_per_launch": probes_per_launch,
                          "cells_read_per_launch": cells_read_per_launch, "geometry": args.geometry,
                          "fullsize_parity_vs_reference_geometry": xcheck,

@@ -168,16 +168,23 @@ int kid_classify_wait(kid_sample *s, uint64_t ticket);
 /* pinned (page-locked) host memory for the buffers above, placed on the NUMA node `device` is attached to */
 int kid_host_alloc(int device, uint64_t nbytes, void **ptr);
 int kid_host_free(void *ptr);
-/* Device-resident form, asynchronous on `stream` (a hipStream_t, NULL = default
- * stream).  A sample has ONE set of scratch buffers: batches handed over on different
- * streams are ordered behind each other by the library (an event wait), they do not overlap.  bases_nbytes = offsets[n_reads] (size of the read text); d_bases must be
- * 16-byte aligned and its allocation must extend at least 16 bytes past bases_nbytes
- * (the pack kernel reads aligned 16-byte chunks).                                 */
+/* Device-resident form, asynchronous on `stream` (a hipStream_t, NULL = default stream).
+ *   d_bases    the ASCII read text in HBM; the classify kernels read it AS IT IS (there is no packed copy): it must be
+ *              16-byte aligned, its allocation must extend at least 16 bytes past bases_nbytes (= offsets[n_reads]), and it
+ *              must stay untouched until the batch is through -- i.e. until everything queued on `stream` up to this
+ *              call has run, not just until the call returns
+ *   d_offsets, d_start, d_stop  read by a small kernel in front of the classify kernels (read descriptors, range checks);
+ *              the same lifetime.  The library keeps three sets of descriptor scratch and uses them in turn; the classify
+ *              kernels of a sample's batches never overlap each other (batches handed over on different streams are ordered
+ *              behind each other by an event wait).  Under KID_OPT_INPUTS_READY the descriptor kernel of batch b + 1 may
+ *              run while batch b is being classified.
+ *   Records of more than KID_OPT_LONG_RECORD_KMERS k-mers are sorted out on the device and take the long-record kernels. */
 int kid_classify_batch_device(kid_sample *s, const void *d_bases, uint64_t bases_nbytes,
                               const void *d_offsets, const void *d_start, const void *d_stop,
                               uint64_t n_reads, void *d_out_final_targ, void *stream);
-/* Fixed-length reads laid out back to back (read r = bases[r*read_len, (r+1)*read_len)),
- * whole reads, no offsets array: the layout of the synthetic roofline runs.      */
+/* Fixed-length reads laid out back to back (read r = bases[r*read_len, (r+1)*read_len)), whole reads, no offsets
+ * array: the layout of the synthetic roofline runs.  One kernel launch per batch (no descriptors, nothing in front of
+ * the classify kernel); the same alignment / lifetime rules for d_bases.                                            */
 int kid_classify_fixed_device(kid_sample *s, const void *d_bases, uint32_t read_len,
                               uint64_t n_reads, void *d_out_final_targ, void *stream);
 
@@ -190,10 +197,11 @@ int kid_trim_batch(kid_db *db, const uint8_t *quals, const uint64_t *offsets, ui
  * gcount[ntar], ucount[ntar] as written to <prefix>_result.txt (:1040-1043).
  * Synchronises the sample's outstanding work first.                             */
 int kid_sample_end(kid_sample *s, int64_t *gcount, int64_t *ucount);
-/* The same for ONE sample whose batches were dealt out over n kid_sample objects, one per GPU, each on its own
- * replica of the database (kid_db_replicate): gcount summed, ucount from the union of the seen-bitmaps (copied peer
- * to peer to samples[0]'s GPU).  Replaces the per-sample reset + write of main (newkmer_10nx.cpp:1015-1045) around
- * N devices; the result is identical for any N and any way of dealing the batches.                              */
+/* The same for ONE sample whose batches were dealt out over n DISTINCT kid_sample objects (a sample named twice is
+ * KID_ERR_ARG: its reads would count twice), one per GPU, each on its own replica of the database (kid_db_replicate):
+ * gcount summed, ucount from the union of the seen-bitmaps (copied peer to peer to samples[0]'s GPU).  Replaces the
+ * per-sample reset + write of main (newkmer_10nx.cpp:1015-1045) around N devices; the result is identical for any N
+ * and any way of dealing the batches.                                                                           */
 int kid_sample_end_merged(kid_sample **samples, int n, int64_t *gcount, int64_t *ucount);
 /* {reads, k-mer lookups, table cells read, k-mer hits} so far (synchronises) */
 int kid_sample_stats(kid_sample *s, uint64_t out[4]);
@@ -224,39 +232,10 @@ int kid_sample_gcount(kid_sample *s, int64_t *gcount);
  * 8 * kid_sample_seen_bytes (byte ranges of the bitmap helpers above are multiples of 16) */
 int kid_sample_ucount_range(kid_sample *s, uint64_t bit_begin, uint64_t bit_end, int64_t *ucount);
 
-/* ---- synthetic workload generators (bench + tests; deterministic, seeded) ------
- * DB key j = canonical(splitmix64(seed + j) mod 4^k); target of key j follows
- * cum[] (cum[t] <= j < cum[t+1]).  Reads: see DESIGN.md "synthetic workload".    */
-int kid_synth_db_keys_host(uint64_t seed, int k, const uint64_t *cum, int32_t ntar,
-                           uint64_t j0, uint64_t n, uint64_t *keys, uint32_t *targets);
-int kid_synth_db_keys_device(uint64_t seed, int k, const uint64_t *cum_host, int32_t ntar,
-                             uint64_t j0, uint64_t n, void *d_keys, void *d_targets, int device);
-int kid_synth_reads_host(uint64_t db_seed, uint64_t read_seed, int k, const uint64_t *cum,
-                         const int32_t *parent, int32_t ntar, uint64_t r0, uint64_t n_reads,
-                         uint32_t read_len, uint8_t *bases);
-int kid_synth_reads_device(uint64_t db_seed, uint64_t read_seed, int k, const uint64_t *cum_host,
-                           const int32_t *parent_host, int32_t ntar, uint64_t r0, uint64_t n_reads,
-                           uint32_t read_len, void *d_bases, int device);
-
-/* random gather micro-benchmark over the DB's own table: the measured ceiling the
- * lookup kernel is priced against.  inflight = 101 / 108: random 128-byte LINES,
- * one 16-byte load per lane as the classify kernel issues it (64 distinct lines per
- * load / runs of 8 lanes on a line), four loads in flight per lane; *loads_out = the
- * distinct line requests of one launch.  inflight = 1,2,4,8: n_loads random cells,
- * that many independent loads per lane, of which the compiler keeps two 4-byte
- * loads per cell (the round-1 probe: twice the load instructions per line, it tops
- * out at 39 G cells/s where the line probe reaches 49 G lines/s).
- * *ms_out = milliseconds per launch.                                               */
-int kid_bench_gather(kid_db *db, uint64_t n_loads, int inflight, int iters, float *ms_out, uint64_t *loads_out);
-
-/* device memory helpers so that a host language without a HIP binding can stage buffers */
-int kid_dev_alloc(int device, uint64_t nbytes, void **d_ptr);
-int kid_dev_free(int device, void *d_ptr);
-int kid_dev_upload(int device, void *d_dst, const void *src, uint64_t nbytes);
-int kid_dev_download(int device, void *dst, const void *d_src, uint64_t nbytes);
-int kid_dev_sync(int device);
-
+/* (The synthetic workload generators, the random-gather probe and the device memory helpers that bench.py and the
+ *  tests use live in kmer_id_amd_bench.h: they are not part of the boundary.)                                        */
 #ifdef __cplusplus
 }
 #endif
+#include "kmer_id_amd_bench.h"
 #endif /* KMER_ID_AMD_H */

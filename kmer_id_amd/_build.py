@@ -36,7 +36,7 @@ def _newer(target, sources):
 
 def lib_sources():
     return [os.path.join(CSRC, f) for f in ("kid_api.hip", "kid_kernels.hip.h", "kid_common.h")] + [
-        os.path.join(ROOT, "include", "kmer_id_amd.h")]
+        os.path.join(ROOT, "include", "kmer_id_amd.h"), os.path.join(ROOT, "include", "kmer_id_amd_bench.h")]
 
 
 def build_library(force=False, verbose=False):

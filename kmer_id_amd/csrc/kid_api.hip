@@ -57,13 +57,6 @@ struct KidEvent {
     hipEvent_t release() { hipEvent_t r = e; e = nullptr; return r; }
 };
 
-// the long records of a host batch that go through kid_long_hits_kernel / kid_long_fold_kernel
-struct KidLongPlan {
-    std::vector<KidLongRec> recs;
-    uint64_t total_kmers = 0, n_tiles = 0;
-    uint32_t cut = 0; // reads with more k-mers than this are in `recs`
-};
-
 struct kid_db {
     int device = 0;
     int num_cu = 0;
@@ -97,9 +90,8 @@ struct kid_sample {
     struct Scratch {
         KidReadDesc *desc = nullptr;
         uint64_t desc_cap = 0;
-        uint32_t *codes = nullptr;
-        uint16_t *inval = nullptr;
-        uint64_t chunks_cap = 0;
+        KidLongList *long_list = nullptr; // very long records of the batch: flagged by the prepare kernel ...
+        KidLongPlan *long_plan = nullptr; // ... placed by kid_long_plan_kernel (allocated with the first batch that can hold one)
         KidRareArgs *rare = nullptr;  // device copy, written in kid_sample_begin (per batch: batch_max, desc, out_final)
         hipEvent_t ev_prep = nullptr; // the prepare kernel (+ pack) of the batch using the set is done
         hipEvent_t ev_used = nullptr; // ... its classify kernels are done: the set may be overwritten (recorded when a pack on another stream asks)
@@ -129,9 +121,7 @@ struct kid_sample {
     double log_entries_per_read = 4.0; // pace of the passes: a guess until the first pass has reported
     uint64_t reads_of_last_pass = 0;
     unsigned long long last_seen_host_total = 0;
-    // very long records of host batches: their list and one word per k-mer position for the hits
-    KidLongRec *long_recs = nullptr;
-    uint64_t long_recs_cap = 0;
+    // very long records: one word per k-mer position for the hits
     uint32_t *long_hits = nullptr;
     uint64_t long_hits_cap = 0;
     uint8_t *long_tiles = nullptr; // "this tile of 256 positions holds a hit"
@@ -154,7 +144,6 @@ struct kid_sample {
         uint64_t recs_cap = 0;
         hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_out = nullptr;
         std::vector<uint64_t> rel; // offsets rebased to the slot (alive until the copy has been issued AND done)
-        KidLongPlan plan;          // the batch's very long records
         uint64_t ticket = 0;
         bool busy = false;
     };
@@ -605,13 +594,12 @@ extern "C" void kid_sample_destroy(kid_sample *s)
     for (kid_sample::Scratch &sc : s->sets) {
         if (sc.rare) hipFree(sc.rare);
         if (sc.desc) hipFree(sc.desc);
-        if (sc.codes) hipFree(sc.codes);
-        if (sc.inval) hipFree(sc.inval);
+        if (sc.long_list) hipFree(sc.long_list);
+        if (sc.long_plan) hipFree(sc.long_plan);
         if (sc.ev_prep) hipEventDestroy(sc.ev_prep);
         if (sc.ev_used) hipEventDestroy(sc.ev_used);
     }
     if (s->prep_stream) hipStreamDestroy(s->prep_stream);
-    if (s->long_recs) hipFree(s->long_recs);
     if (s->long_hits) hipFree(s->long_hits);
     if (s->long_tiles) hipFree(s->long_tiles);
     if (s->rare_fixed) hipFree(s->rare_fixed);
@@ -729,6 +717,8 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
 // lives in LDS when 4 workgroups per CU still fit).  The kernels read the caller's ASCII text directly.
 // max_kmers: the largest n_kmers of the batch when the host knows it (then only the kernel the batch is for is
 // launched), -1 when only the device does
+// long_records: the batch may hold records of more than s->long_kmers k-mers (FASTA contigs): those take the
+// long-record kernels; the host does not need to know which they are
 // prep_stream: where the prepare kernel runs.  The same as `stream` unless the read text is known to be ready earlier
 // than stream order says (host path: the copy stream behind the upload; kid_classify_batch_device under
 // KID_OPT_INPUTS_READY: an internal stream) -- then it overlaps with the classify kernels of the batch before.
@@ -790,14 +780,16 @@ struct KidFastqIn {
     const KidFastqRec *recs;
 };
 static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_nbytes, hipStream_t stream, int64_t max_kmers,
-                               hipStream_t prep_stream, const KidLongPlan *plan = nullptr, const KidFastqIn *fastq = nullptr)
+                               hipStream_t prep_stream, bool long_records = false, const KidFastqIn *fastq = nullptr)
 {
     kid_db *db = s->db;
     if (b.n == 0) return KID_OK;
     if (b.n > 0x7FFFFFFFull) return kid_fail(KID_ERR_ARG, "at most 2^31-1 reads per batch");
     if (bases_nbytes >> 48) return kid_fail(KID_ERR_ARG, "a batch of 2^48 bytes or more");
     const bool fixed = b.offsets == nullptr && !fastq; // fixed layout: whole reads of b.fixed_len bases back to back
-    const bool have_plan = plan && !plan->recs.empty();
+    const uint32_t long_cut = (long_records && !fastq && s->long_kmers > 0 && s->long_kmers < 0xFFFFFFFFll &&
+                               bases_nbytes > (uint64_t)s->long_kmers) ? (uint32_t)s->long_kmers : 0u;
+    if (long_cut) max_kmers = -1; // (the host's number counts the hidden records too: the device's does not)
     // The classify kernels of a sample's batches run one after the other (they share the sample's counters' timing
     // stamps and argument blocks): a batch issued on another stream than the one before is made to wait for it.
     if (s->has_last_stream && s->last_stream != stream) {
@@ -817,21 +809,33 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
         kid_sample::Scratch &sc = s->sets[s->next_set++ % kid_sample::NSET];
         scp = &sc;
         rare = sc.rare;
-        const uint64_t nchunks = have_plan ? (bases_nbytes + 15) / 16 : 0;
-        if (b.n > sc.desc_cap || nchunks > sc.chunks_cap) KID_HIP(hipDeviceSynchronize()); // (scratch in use is not freed)
+        if (b.n > sc.desc_cap) KID_HIP(hipDeviceSynchronize()); // (scratch in use is not freed)
         if (b.n > sc.desc_cap) {
             if (sc.desc) hipFree(sc.desc);
             sc.desc = nullptr; sc.desc_cap = 0;
             KID_HIP(hipMalloc(&sc.desc, b.n * sizeof(KidReadDesc)));
             sc.desc_cap = b.n;
         }
-        if (nchunks > sc.chunks_cap) { // the packed image the long-record kernels index by position
-            if (sc.codes) hipFree(sc.codes);
-            if (sc.inval) hipFree(sc.inval);
-            sc.codes = nullptr; sc.inval = nullptr; sc.chunks_cap = 0;
-            KID_HIP(hipMalloc(&sc.codes, (nchunks + 64) * 4));
-            KID_HIP(hipMalloc(&sc.inval, (nchunks + 64) * 2));
-            sc.chunks_cap = nchunks;
+        if (long_cut) {
+            if (!sc.long_list) {
+                KID_HIP(hipMalloc(&sc.long_list, sizeof(KidLongList)));
+                KID_HIP(hipMalloc(&sc.long_plan, sizeof(KidLongPlan)));
+                KID_HIP(hipMemset(sc.long_list, 0, 16));
+            }
+            // one word per k-mer position of the long records, one flag per 256: as many as the batch has bases (a bound
+            // the host knows), at most 128 M (records beyond that stay with the classify kernels)
+            const uint64_t want = bases_nbytes < (128ull << 20) ? bases_nbytes : (128ull << 20);
+            if (want > s->long_hits_cap) {
+                KID_HIP(hipDeviceSynchronize());
+                if (s->long_hits) hipFree(s->long_hits);
+                if (s->long_tiles) hipFree(s->long_tiles);
+                s->long_hits = nullptr; s->long_tiles = nullptr; s->long_hits_cap = 0; s->long_tiles_cap = 0;
+                const uint64_t cap = want + want / 4;
+                KID_HIP(hipMalloc(&s->long_hits, cap * 4));
+                KID_HIP(hipMalloc(&s->long_tiles, cap / 256 + KID_LONG_MAX + 16));
+                s->long_hits_cap = cap;
+                s->long_tiles_cap = cap / 256 + KID_LONG_MAX;
+            }
         }
         // The batch that used this set three batches ago must be through its classify kernels before the set is overwritten.
         // On the stream those kernels ran on that is a matter of stream order; only a different prepare stream needs an
@@ -846,20 +850,20 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
             }
         }
         const bool fuse_rebase = prep_stream == stream;
-        if (nchunks)
-            hipLaunchKernelGGL(kid_pack_kernel, dim3(kid_grid_for(nchunks, 256, db->num_cu * 16)), dim3(256), 0, prep_stream, b.bases,
-                               nchunks, db->d.u_is_t, sc.codes, sc.inval);
         if (fastq)
             hipLaunchKernelGGL(kid_prepare_fastq_kernel, dim3(kid_grid_for(b.n, 256, db->num_cu * 8)), dim3(256), 0, prep_stream, b.bases,
                                fastq->recs, b.n, db->info.k, sc.desc, const_cast<int32_t *>(b.start), const_cast<int32_t *>(b.stop),
                                b.out_final, s->stats, s->gcount, sc.rare, ++s->batch_seq, fuse_rebase ? 1 : 0);
         else
             hipLaunchKernelGGL(kid_prepare_kernel, dim3(kid_grid_for(b.n, 256, db->num_cu * 8)), dim3(256), 0, prep_stream, b, db->info.k,
-                               sc.desc, s->stats, sc.rare, ++s->batch_seq, have_plan ? plan->cut : 0u, fuse_rebase ? 1 : 0);
+                               sc.desc, s->stats, sc.rare, ++s->batch_seq, long_cut, sc.long_list, fuse_rebase ? 1 : 0);
         if (prep_stream != stream) {
             KID_HIP(hipEventRecord(sc.ev_prep, prep_stream));
             KID_HIP(hipStreamWaitEvent(stream, sc.ev_prep, 0));
         }
+        if (long_cut) // the flagged records -> their places in the hit array (in classify-stream order, before the kernels)
+            hipLaunchKernelGGL(kid_long_plan_kernel, dim3(1), dim3(64), 0, stream, sc.long_list, sc.long_plan, sc.desc, sc.rare, s->batch_seq,
+                               s->long_hits_cap, s->long_tiles_cap);
     }
     const int block = 512, wpb = block / 64;
     const uint32_t ntar = (uint32_t)db->info.ntar;
@@ -954,38 +958,14 @@ static int kid_launch_classify(kid_sample *s, const KidBatch &b, uint64_t bases_
 #undef KID_LAUNCH1
 #undef KID_LAUNCH
     }
-    if (have_plan) {
-        kid_sample::Scratch &sc = *scp; // (long records only come with offsets: never a fixed-layout batch)
-        // the very long records: every k-mer looked up by a lane of its own, then one workgroup per record folds its hits
-        const uint64_t nrec = plan->recs.size();
-        if (nrec > s->long_recs_cap || plan->total_kmers > s->long_hits_cap || plan->n_tiles > s->long_tiles_cap) KID_HIP(hipDeviceSynchronize());
-        if (plan->n_tiles > s->long_tiles_cap) {
-            if (s->long_tiles) hipFree(s->long_tiles);
-            s->long_tiles = nullptr; s->long_tiles_cap = 0;
-            const uint64_t cap = plan->n_tiles + plan->n_tiles / 4 + 16;
-            KID_HIP(hipMalloc(&s->long_tiles, cap));
-            s->long_tiles_cap = cap;
-        }
-        if (nrec > s->long_recs_cap) {
-            if (s->long_recs) hipFree(s->long_recs);
-            s->long_recs = nullptr; s->long_recs_cap = 0;
-            KID_HIP(hipMalloc(&s->long_recs, nrec * sizeof(KidLongRec)));
-            s->long_recs_cap = nrec;
-        }
-        if (plan->total_kmers > s->long_hits_cap) {
-            if (s->long_hits) hipFree(s->long_hits);
-            s->long_hits = nullptr; s->long_hits_cap = 0;
-            const uint64_t cap = plan->total_kmers + plan->total_kmers / 4;
-            KID_HIP(hipMalloc(&s->long_hits, cap * 4));
-            s->long_hits_cap = cap;
-        }
-        KID_HIP(hipMemcpyAsync(s->long_recs, plan->recs.data(), nrec * sizeof(KidLongRec), hipMemcpyHostToDevice, stream));
-        KID_HIP(hipMemsetAsync(s->long_hits, 0, plan->total_kmers * 4, stream));
-        const uint64_t hgrid = plan->n_tiles < (uint64_t)db->num_cu * 8u ? plan->n_tiles : (uint64_t)db->num_cu * 8u;
-        hipLaunchKernelGGL(kid_long_hits_kernel, dim3((unsigned)hgrid), dim3(256), 0, stream, db->d, sc.codes, sc.inval, s->long_recs,
-                           (uint32_t)nrec, plan->n_tiles, s->long_hits, s->long_tiles, s->seen, s->stats);
-        hipLaunchKernelGGL(kid_long_fold_kernel, dim3((unsigned)nrec), dim3(256), 0, stream, db->d, s->long_recs, s->long_hits,
-                           s->long_tiles, s->gcount, b.out_final);
+    if (long_cut) {
+        // the very long records: every k-mer looked up by a lane of its own, then one workgroup per record folds its hits.
+        // (The grids do not depend on how many there are -- only the device knows: without any, the kernels return at once.)
+        kid_sample::Scratch &sc = *scp;
+        hipLaunchKernelGGL(kid_long_hits_kernel, dim3((unsigned)db->num_cu * 8u), dim3(256), 0, stream, db->d, b.bases, sc.long_plan,
+                           s->long_hits, s->long_tiles, s->seen, s->stats);
+        hipLaunchKernelGGL(kid_long_fold_kernel, dim3(KID_LONG_MAX), dim3(256), 0, stream, db->d, sc.long_plan, s->long_hits, s->long_tiles,
+                           s->gcount, b.out_final);
     }
     if (s->timing) {
         KID_HIP(hipEventRecord(ev1.e, stream));
@@ -1095,7 +1075,7 @@ extern "C" int kid_classify_batch_device(kid_sample *s, const void *d_bases, uin
     hipStream_t prep;
     rc = kid_prep_stream_for(s, (hipStream_t)stream, &prep);
     if (rc != KID_OK) return rc;
-    return kid_launch_classify(s, b, bases_nbytes, (hipStream_t)stream, -1, prep);
+    return kid_launch_classify(s, b, bases_nbytes, (hipStream_t)stream, -1, prep, /*long_records=*/true);
 }
 
 extern "C" int kid_classify_fixed_device(kid_sample *s, const void *d_bases, uint32_t read_len, uint64_t n_reads,
@@ -1134,7 +1114,6 @@ static int kid_slot_acquire(kid_sample *s, uint64_t n_reads, uint64_t nbytes, bo
         KID_HIP(hipEventSynchronize(sl.ev_out));
         sl.busy = false;
     }
-    sl.plan = KidLongPlan();
     const uint64_t need = ((nbytes + 15) & ~15ull) + 32;
     if (need > sl.bases_cap) {
         if (sl.bases) KID_HIP(hipFree(sl.bases));
@@ -1163,14 +1142,14 @@ static int kid_slot_acquire(kid_sample *s, uint64_t n_reads, uint64_t nbytes, bo
 
 // upload issued on the copy stream -> kernels on the sample's stream -> results on the result stream
 static int kid_slot_submit(kid_sample *s, kid_sample::Slot &sl, const KidBatch &b, uint64_t nbytes, int64_t max_kmers,
-                           uint32_t *out_final_targ, uint64_t *ticket)
+                           uint32_t *out_final_targ, uint64_t *ticket, bool long_records = false)
 {
     // the prepare kernel follows the upload on the copy stream (beside the classify kernels of the batch before); the
     // classify kernels wait for it on the sample's stream
     KID_HIP(hipEventRecord(sl.ev_h2d, s->copy_stream));
     // (a fixed-layout batch has no prepare kernel on the copy stream for the classify kernels to wait for: they wait for the upload itself)
     if (!b.offsets) KID_HIP(hipStreamWaitEvent(s->stream, sl.ev_h2d, 0));
-    int rc = kid_launch_classify(s, b, nbytes, s->stream, max_kmers, s->copy_stream, sl.plan.recs.empty() ? nullptr : &sl.plan);
+    int rc = kid_launch_classify(s, b, nbytes, s->stream, max_kmers, s->copy_stream, long_records);
     if (rc != KID_OK) return rc;
     KID_HIP(hipEventRecord(sl.ev_done, s->stream));
     if (out_final_targ) {
@@ -1194,13 +1173,9 @@ extern "C" int kid_classify_batch_async(kid_sample *s, const uint8_t *bases, con
     if (n_reads == 0) return KID_OK;
     if (!bases || !offsets) return kid_fail(KID_ERR_ARG, "null argument");
     if ((start == nullptr) != (stop == nullptr)) return kid_fail(KID_ERR_ARG, "start and stop must both be given or both be null");
-    // A record of more than `long_cut` k-mers is a long record (a FASTA contig, kmer_read_vf6.cpp:803-861): the classify
-    // kernels would give it to one wave.  If the batch holds few of them they go through the long-record kernels
-    // instead; if it holds many, the waves have enough of them to keep the chip busy as it is.
-    const int64_t long_cut = s->long_kmers;
-    static const size_t long_max = 1024;
-    int64_t max_kmers = 0, max_short = 0;
-    std::vector<KidLongRec> longs;
+    // A record of more than s->long_kmers k-mers is a long record (a FASTA contig, kmer_read_vf6.cpp:803-861): the classify
+    // kernels would give it to one wave; the launch sorts those out on the device (kid_long_*).
+    int64_t max_kmers = 0;
     for (uint64_t r = 0; r < n_reads; r++) {
         if (offsets[r + 1] < offsets[r]) return kid_fail(KID_ERR_ARG, "offsets not monotone at read %llu", (unsigned long long)r);
         const uint64_t len = offsets[r + 1] - offsets[r];
@@ -1211,18 +1186,8 @@ extern "C" int kid_classify_batch_async(kid_sample *s, const uint8_t *bases, con
         if (start && start[r] <= stop[r] && (start[r] < 0 || (uint64_t)stop[r] >= len))
             return kid_fail(KID_ERR_ARG, "read %llu: [start,stop] = [%d,%d] outside the read of length %llu (string::at would throw)",
                             (unsigned long long)r, start[r], stop[r], (unsigned long long)len);
-        if (long_cut > 0 && nk > long_cut) {
-            if (longs.size() <= long_max) {
-                KidLongRec lr;
-                lr.first_base = (offsets[r] - offsets[0]) + (uint64_t)(start ? start[r] : 0);
-                lr.hits_off = 0; lr.tile0 = 0;
-                lr.n_kmers = (uint32_t)nk;
-                lr.read = (uint32_t)r;
-                longs.push_back(lr);
-            }
-        } else if (nk > max_short) max_short = nk;
     }
-    const bool two_pass = !longs.empty() && longs.size() <= long_max && (int64_t)(uint32_t)long_cut == long_cut;
+    const bool long_records = s->long_kmers > 0 && max_kmers > s->long_kmers;
     int rc = kid_use_device(s->db->device);
     if (rc != KID_OK) return rc;
     const uint64_t base0 = offsets[0], nbytes = offsets[n_reads] - base0;
@@ -1231,18 +1196,6 @@ extern "C" int kid_classify_batch_async(kid_sample *s, const uint8_t *bases, con
     if (rc != KID_OK) return rc;
     kid_sample::Slot &sl = *slp;
     hipStream_t cs = s->copy_stream;
-    sl.plan = KidLongPlan();
-    if (two_pass) {
-        sl.plan.cut = (uint32_t)long_cut;
-        for (KidLongRec &lr : longs) {
-            lr.hits_off = sl.plan.total_kmers;
-            lr.tile0 = sl.plan.n_tiles;
-            sl.plan.total_kmers += lr.n_kmers;
-            sl.plan.n_tiles += ((uint64_t)lr.n_kmers + 255u) / 256u;
-        }
-        sl.plan.recs = std::move(longs);
-        max_kmers = max_short; // what the classify kernels get to see
-    }
     const uint64_t *off_src = offsets;
     if (base0 != 0) {
         sl.rel.resize(n_reads + 1);
@@ -1264,7 +1217,7 @@ extern "C" int kid_classify_batch_async(kid_sample *s, const uint8_t *bases, con
     b.stop = start ? sl.stop : nullptr;
     b.out_final = sl.out;
     b.n = n_reads;
-    return kid_slot_submit(s, sl, b, nbytes, max_kmers, out_final_targ, ticket);
+    return kid_slot_submit(s, sl, b, nbytes, max_kmers, out_final_targ, ticket, long_records);
 }
 
 extern "C" int kid_classify_fixed_async(kid_sample *s, const uint8_t *bases, uint32_t read_len, uint64_t n_reads,
@@ -1335,7 +1288,7 @@ extern "C" int kid_classify_fastq_async(kid_sample *s, const uint8_t *text, uint
     b.n = n_reads;
     KidFastqIn fq{sl.recs};
     KID_HIP(hipEventRecord(sl.ev_h2d, s->copy_stream));
-    rc = kid_launch_classify(s, b, text_nbytes, s->stream, -1, s->copy_stream, nullptr, &fq);
+    rc = kid_launch_classify(s, b, text_nbytes, s->stream, -1, s->copy_stream, false, &fq);
     if (rc != KID_OK) return rc;
     KID_HIP(hipEventRecord(sl.ev_done, s->stream));
     KID_HIP(hipStreamWaitEvent(s->out_stream, sl.ev_done, 0));

@@ -103,6 +103,31 @@ struct KidReadDesc {
     uint32_t pad;
 };
 
+// Very long records (FASTA contigs classified whole, kmer_read_vf6.cpp:803-861).  The classify kernels give a read to ONE
+// wave; a record of more than `long_cut` k-mers goes to the long-record kernels instead (kid_long_*): kid_prepare_kernel
+// hides it from the classify kernels (n_kmers = 0) and puts it on this list, kid_long_plan_kernel turns the list into
+// the records' places in the hit array.  All on the device: the batch may be one whose offsets the host never saw.
+#define KID_LONG_MAX 1024u
+struct KidLongList {
+    uint32_t n;       // records flagged so far (beyond KID_LONG_MAX: left to the classify kernels)
+    uint32_t pad[3];
+    struct Item { uint64_t first_base; uint32_t n_kmers; uint32_t read; } e[KID_LONG_MAX];
+};
+struct KidLongRec {
+    uint64_t first_base; // absolute index of the record's first classified base in the batch text
+    uint64_t hits_off;   // where its hits start in the hits array
+    uint32_t n_kmers;
+    uint32_t read;       // its number in the batch
+    uint64_t tile0;      // number of 256-position tiles of the records before it
+};
+struct KidLongPlan {
+    uint32_t n_recs;
+    uint32_t pad;
+    uint64_t n_tiles;
+    uint64_t total_kmers;
+    KidLongRec recs[KID_LONG_MAX];
+};
+
 // What a launch of the classify kernels reads: the ASCII read text as the caller handed it over -- the kernels turn it
 // into 2-bit codes in registers (kid_pack4 / kid_pack16), there is no packed image of the batch in memory -- and the
 // reads' descriptors.  Fixed layout (kid_classify_fixed_*): no descriptors either, read r of the launch is
@@ -357,7 +382,7 @@ __device__ __forceinline__ void kid_rebase(KidRareArgs *rare, const KidReadDesc 
 
 // [start, stop] -> descriptor; the range checks the reference leaves to string::at() happen here
 __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, unsigned long long *stats, KidRareArgs *rare, uint32_t seq,
-                                   uint32_t long_cut, int rebase)
+                                   uint32_t long_cut, KidLongList *long_list, int rebase)
 {
     // (the launch's descriptor / result pointers are set in classify-stream order: by kid_rebase_kernel when this kernel
     //  may run while the batch before is being classified, else -- `rebase`, same stream -- right here for the batch's
@@ -384,7 +409,15 @@ __global__ void kid_prepare_kernel(const KidBatch b, int k, KidReadDesc *desc, u
         d.pad = 0;
         // a record that goes to the long-record kernels (kid_long_hits_kernel / kid_long_fold_kernel): the classify
         // kernels see a read without k-mers (counted under target 0 until the fold corrects that)
-        if (long_cut && nk > (int64_t)long_cut) d.n_kmers = 0;
+        if (long_cut && nk > (int64_t)long_cut) {
+            const uint32_t at = atomicAdd(&long_list->n, 1u);
+            if (at < KID_LONG_MAX) {
+                KidLongList::Item it;
+                it.first_base = d.first_base; it.n_kmers = (uint32_t)d.n_kmers; it.read = (uint32_t)r;
+                long_list->e[at] = it;
+                d.n_kmers = 0;
+            }
+        }
         desc[r] = d;
         if (d.n_kmers > 0 && (uint32_t)d.n_kmers > mx) mx = (uint32_t)d.n_kmers;
     }
@@ -413,19 +446,6 @@ __global__ void kid_rebase_kernel(KidRareArgs *rare, const KidReadDesc *desc, ui
 {
     kid_rebase(rare, desc, out_final, read0, fixed_len, fixed_nk);
     if (threadIdx.x == 0 && batch_max) rare->batch_max = batch_max;
-}
-
-// ASCII -> 2 bits per base + invalid mask for a whole batch buffer, 16 bases per lane: the packed image the
-// long-record kernels index by position (kid_long_hits_kernel); the classify kernels pack in registers
-__global__ void kid_pack_kernel(const uint8_t *bases, uint64_t nchunks, uint32_t u_is_t, uint32_t *codes, uint16_t *inval)
-{
-    for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < nchunks; c += (uint64_t)gridDim.x * blockDim.x) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(bases + 16ull * c);
-        uint32_t w, m;
-        kid_pack16(v, u_is_t, w, m);
-        codes[c] = w;
-        inval[c] = (uint16_t)m;
-    }
 }
 
 // ------------------------------------------------------------------ classify
@@ -1819,25 +1839,54 @@ __global__ void kid_build_firstwins_kernel(uint4 *table, uint32_t slot_mask, con
 //   kid_long_fold_kernel   one workgroup per record compacts the hits in position order and folds them, 64 at a time,
 //                          jumping from change to change of the running result like the resolver does
 // Plain code: this path runs a few hundred times per batch, not a hundred million times.
-struct KidLongRec {
-    uint64_t first_base; // absolute index of the record's first classified base in the batch text
-    uint64_t hits_off;   // where its hits start in the hits array
-    uint32_t n_kmers;
-    uint32_t read;       // its number in the batch
-    uint64_t tile0;      // number of 256-position tiles of the records before it
-};
+// The list -> the plan: where every long record's hits go.  One thread: the list is short.  A record that does not fit
+// the hit array any more is handed back to the classify kernels (its descriptor gets its k-mers back).
+__global__ void kid_long_plan_kernel(KidLongList *list, KidLongPlan *plan, KidReadDesc *desc, KidRareArgs *rare, uint32_t seq,
+                                     uint64_t hits_cap, uint64_t tiles_cap)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t n = list->n < KID_LONG_MAX ? list->n : KID_LONG_MAX;
+    uint64_t off = 0, tiles = 0;
+    uint32_t m = 0, back = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const KidLongList::Item it = list->e[i];
+        const uint64_t nt = ((uint64_t)it.n_kmers + 255u) / 256u;
+        if (off + it.n_kmers > hits_cap || tiles + nt > tiles_cap) {
+            desc[it.read].n_kmers = (int32_t)it.n_kmers;
+            back = it.n_kmers > back ? it.n_kmers : back;
+            continue;
+        }
+        KidLongRec r;
+        r.first_base = it.first_base; r.hits_off = off; r.n_kmers = it.n_kmers; r.read = it.read; r.tile0 = tiles;
+        plan->recs[m++] = r;
+        off += it.n_kmers;
+        tiles += nt;
+    }
+    plan->n_recs = m;
+    plan->n_tiles = tiles;
+    plan->total_kmers = off;
+    list->n = 0; // for the batch that uses this set next
+    if (back) { // (the kernels pick themselves by the longest read of the batch)
+        const unsigned long long v = ((unsigned long long)seq << 32) | back;
+        if (v > rare->batch_max) rare->batch_max = v;
+    }
+}
 
-__device__ __forceinline__ uint32_t kid_codes_word(const uint32_t *codes, uint64_t w) { return codes[w]; }
-
-__global__ __launch_bounds__(256) void kid_long_hits_kernel(const KidDevDb db, const uint32_t *codes, const uint16_t *inval,
-                                                             const KidLongRec *recs, uint32_t n_recs, uint64_t n_tiles,
+// Every k-mer of every long record is looked up by a lane of its own.  A tile = 256 consecutive k-mers of one record:
+// its 256 + k - 1 bases are read as text (16 bytes per thread by the first 20 threads), packed in registers and staged
+// in LDS, like the classify kernels' general loops stage a segment.
+__global__ __launch_bounds__(256) void kid_long_hits_kernel(const KidDevDb db, const uint8_t *bases, const KidLongPlan *plan,
                                                              uint32_t *hits, uint8_t *tile_any, uint32_t *seen,
                                                              unsigned long long *stats)
 {
     __shared__ uint32_t mm[256 + 32];
+    __shared__ uint32_t W[24], IM[24]; // the tile's packed words and invalid masks (20 chunks + what a window reads beyond)
     const int k = db.k;
     const uint32_t win = (uint32_t)kid_min_window(k);
     const int mlen = kid_min_mlen(k);
+    const uint32_t n_recs = plan->n_recs;
+    const uint64_t n_tiles = plan->n_tiles;
+    const KidLongRec *recs = plan->recs;
     unsigned long long n_lookups = 0, n_cells = 0, n_hits = 0;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         // the record this tile belongs to (recs are few: binary search over tile0)
@@ -1846,28 +1895,42 @@ __global__ __launch_bounds__(256) void kid_long_hits_kernel(const KidDevDb db, c
         const KidLongRec rc = recs[lo];
         const uint32_t t0 = (uint32_t)(tile - rc.tile0) * 256u; // first k-mer of the tile within the record
         const uint32_t j = threadIdx.x;
+        // the tile's text: chunks c0 .. of 16 bases, never beyond the chunk that holds the record's last base
+        const uint64_t c0 = (rc.first_base + t0) >> 4, c_last = (rc.first_base + (uint64_t)rc.n_kmers + (uint64_t)k - 2u) >> 4;
+        if (j < 24u) {
+            uint32_t cw = 0, ci = 0;
+            if (c0 + j <= c_last && j < 21u) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(bases + 16ull * (c0 + j));
+                kid_pack16(v, db.u_is_t, cw, ci);
+            }
+            W[j] = cw;
+            IM[j] = ci;
+        }
+        __syncthreads();
         auto window = [&](uint64_t base) -> uint64_t { // 32 bases starting at `base`, first base in the top bits
-            const uint64_t w0 = base >> 4;
+            const uint32_t w0 = (uint32_t)((base >> 4) - c0);
             const uint32_t o2 = (uint32_t)(base & 15u) * 2u;
-            const uint64_t A = ((uint64_t)codes[w0] << 32) | codes[w0 + 1];
-            const uint64_t B = codes[w0 + 2];
+            const uint64_t A = ((uint64_t)W[w0] << 32) | W[w0 + 1];
+            const uint64_t B = W[w0 + 2];
             return (A << o2) | ((B << o2) >> 32);
         };
         // hashed m-mers of positions t0 .. t0 + 255 + win - 1 (clamped to the last m-mer inside the record)
         const uint64_t last_m = rc.first_base + (uint64_t)rc.n_kmers + (uint64_t)k - 1u - (uint64_t)mlen;
-        for (uint32_t q = j; q < 256u + win - 1u; q += 256u) {
-            uint64_t p = rc.first_base + t0 + q;
-            p = p < last_m ? p : last_m;
-            mm[q] = kid_mmer_hash((uint32_t)(window(p) >> (64 - 2 * mlen)), mlen);
-        }
+        if (db.minloc) // (workgroup-uniform; the reference placement has no minimizers, and for k < 15 there is no m-mer to hash)
+            for (uint32_t q = j; q < 256u + win - 1u; q += 256u) {
+                uint64_t p = rc.first_base + t0 + q;
+                p = p < last_m ? p : last_m;
+                mm[q] = kid_mmer_hash((uint32_t)(window(p) >> (64 - 2 * mlen)), mlen);
+            }
         __syncthreads();
         const uint32_t i = t0 + j;
         bool hit = false;
+        uint32_t hit_t = 0;
         if (i < rc.n_kmers) {
             const uint64_t p = rc.first_base + i;
             // a window touching a base that is not ACGTacgt(Uu) holds no k-mer (newkmer_10nx.cpp:520-526,604)
-            const uint64_t c0 = p >> 4;
-            uint64_t im = (uint64_t)inval[c0] | ((uint64_t)inval[c0 + 1] << 16) | ((uint64_t)inval[c0 + 2] << 32);
+            const uint32_t iw = (uint32_t)((p >> 4) - c0);
+            uint64_t im = (uint64_t)IM[iw] | ((uint64_t)IM[iw + 1] << 16) | ((uint64_t)IM[iw + 2] << 32);
             im >>= (p & 15u);
             if ((im & ((1ull << k) - 1ull)) == 0) {
                 const uint64_t keyF = window(p) >> (64 - 2 * k);
@@ -1885,12 +1948,13 @@ __global__ __launch_bounds__(256) void kid_long_hits_kernel(const KidDevDb db, c
                 if (tgt > 0) {
                     n_hits++;
                     hit = true;
-                    hits[rc.hits_off + i] = tgt;
                     if (tgt > 1) atomicOr(&seen[slot >> 5], 1u << (slot & 31u));
                 }
+                hit_t = tgt;
             }
         }
-        const int any = __syncthreads_or(hit ? 1 : 0); // (also: mm[] is free for the next tile)
+        if (i < rc.n_kmers) hits[rc.hits_off + i] = hit_t; // (every position: the array is not cleared between batches)
+        const int any = __syncthreads_or(hit ? 1 : 0); // (also: mm[], W[] and IM[] are free for the next tile)
         if (threadIdx.x == 0) tile_any[tile] = any ? 1 : 0; // the fold skips tiles without hits unseen
     }
     // one set of atomics per workgroup (see kid_classify_kernel)
@@ -1904,10 +1968,12 @@ __global__ __launch_bounds__(256) void kid_long_hits_kernel(const KidDevDb db, c
     if (threadIdx.x < 3 && tot[threadIdx.x]) atomicAdd(&stats[1 + threadIdx.x], tot[threadIdx.x]);
 }
 
-__global__ __launch_bounds__(256) void kid_long_fold_kernel(const KidDevDb db, const KidLongRec *recs, const uint32_t *hits,
+__global__ __launch_bounds__(256) void kid_long_fold_kernel(const KidDevDb db, const KidLongPlan *plan, const uint32_t *hits,
                                                              const uint8_t *tile_any, unsigned long long *gcount,
                                                              uint32_t *out_final)
 {
+    if (blockIdx.x >= plan->n_recs) return; // (a grid of KID_LONG_MAX workgroups: the host does not know how many there are)
+    const KidLongRec *recs = plan->recs;
     __shared__ uint32_t list[256];
     __shared__ uint32_t wcount[4];
     __shared__ uint8_t flags[256];

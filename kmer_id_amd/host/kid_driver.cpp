@@ -53,7 +53,28 @@ void load_database(const std::string &tree_path, const std::string &probes_path,
 Engine::~Engine()
 {
     for (kid_sample *s : samples) kid_sample_destroy(s);
-    for (kid_db *d : dbs) kid_db_destroy(d);
+    if (owns_dbs)
+        for (kid_db *d : dbs) kid_db_destroy(d);
+}
+
+std::unique_ptr<Engine> engine_worker(const Engine &owner)
+{
+    std::unique_ptr<Engine> e(new Engine());
+    e->owns_dbs = false;
+    e->dbs = owner.dbs;
+    e->db = owner.db;
+    e->ntar = owner.ntar;
+    e->k = owner.k;
+    e->batch_reads = owner.batch_reads;
+    e->batch_bases = owner.batch_bases;
+    for (kid_db *d : e->dbs) {
+        kid_sample *s = nullptr;
+        int rc = kid_sample_begin(d, &s);
+        if (rc != KID_OK) die_kid(rc);
+        e->samples.push_back(s);
+    }
+    e->sample = e->samples[0];
+    return e;
 }
 
 std::vector<int> parse_devices(const std::string &list)

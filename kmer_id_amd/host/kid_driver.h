@@ -25,8 +25,12 @@ struct Engine {
     size_t batch_reads = 1 << 20;
     size_t batch_bases = 256u << 20;
     double gpu_wait_s = 0, submit_s = 0; // the consumer, inside kid_classify_wait / kid_classify_*_async (--timing)
+    bool owns_dbs = true; // false: a worker of engine_worker() -- its own samples on the owner's databases
     ~Engine();
 };
+// Another set of samples (one per device) on the databases of `owner`: for a thread that classifies another input
+// sample at the same time (nk10 --samples-in-flight).  The owner must outlive it.
+std::unique_ptr<Engine> engine_worker(const Engine &owner);
 
 [[noreturn]] void die_kid(int rc);
 

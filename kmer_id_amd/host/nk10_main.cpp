@@ -14,6 +14,7 @@
 //   --fasta          the reference's compile-time FASTQ=0 mode (:28,:1032-1035): one plain FASTA file
 //                    <prefix><r1 suffix> per sample, read by process_fa (:877-913), no R2 file
 //   --db-cache FILE  binary cache of the parsed database: read if valid, (re)written otherwise
+//   --samples-in-flight N (threads / 2)  samples read and classified at the same time, each with its own counters on the GPU
 //   --timing         one JSON line on stderr when the run ends: seconds of the start-up phases (probes inflate / parse,
 //                    cache read / write, upload + table build on the GPU, first batch classified) and of the read files
 //   --dry-run FILE   host stages only (no GPU): parse the DB text files and the FASTQ files,
@@ -44,6 +45,7 @@ int main(int argc, char **argv)
     bool fasta_mode = false;
     bool parse_only = false; // --parse-only: run the reader pool over the directory without a GPU and report its rate
     bool timing = false;
+    int in_flight = 0; // --samples-in-flight N (0: half the reader threads)
     const auto t_start = std::chrono::steady_clock::now();
     auto since_start = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
     for (int i = 1; i < argc; i++) {
@@ -67,6 +69,7 @@ int main(int argc, char **argv)
         else if (a == "--parse-only") parse_only = true;
         else if (a == "--fasta") fasta_mode = true;
         else if (a == "--timing") timing = true;
+        else if (a == "--samples-in-flight") in_flight = atoi(val("--samples-in-flight"));
         else if (dname.empty()) dname = a;
         else { std::cerr << "nk10: unexpected argument " << a << "\n"; return 2; }
     }
@@ -76,6 +79,8 @@ int main(int argc, char **argv)
     }
     if (!db_dir.empty() && db_dir.back() != '/') db_dir += "/";
     if (batch_reads < 1) batch_reads = 1;
+    if (threads < 1) threads = 1;
+    if (in_flight <= 0) in_flight = threads / 2 > 0 ? threads / 2 : 1; // (a sample = two files = two inflate threads)
 
     try {
         // ---- load the database once (:949-989)
@@ -110,10 +115,10 @@ int main(int argc, char **argv)
                             "\"db_loaded_at_s\": %.3f, \"gpu_upload_and_build_s\": %.3f, \"gpu_ready_at_s\": %.3f, "
                             "\"first_file_classified_at_s\": %.3f, \"total_s\": %.3f, \"log2_slots\": %d, \"devices\": %zu, "
                             "\"consumer_waited_for_host_stages_s\": %.3f, \"consumer_waited_for_gpu_s\": %.3f, \"consumer_submit_s\": %.3f, "
-                            "\"reader_threads\": %d, \"files\": [%s]}}\n",
+                            "\"reader_threads\": %d, \"samples_in_flight\": %d, \"files\": [%s]}}\n",
                     n_entries, from_cache ? "true" : "false", (unsigned long long)tm.text_bytes, tm.inflate_s, tm.parse_wall_s,
                     tm.parse_threads, tm.cache_read_s, tm.cache_write_s, t_db_loaded, tm.gpu_build_s, t_gpu_ready, t_first_file,
-                    since_start(), log2_slots, n_devices, host_wait_s, gpu_wait_s, submit_s, threads, files_json.c_str());
+                    since_start(), log2_slots, n_devices, host_wait_s, gpu_wait_s, submit_s, threads, in_flight, files_json.c_str());
         };
         std::cout << "tree loaded" << std::endl;
         std::cout << ps.lines_parsed << " kmers loaded" << std::endl;
@@ -215,32 +220,103 @@ int main(int argc, char **argv)
             }
         }
         Prefetcher pf(std::move(files), threads, eng.batch_reads, eng.batch_bases);
-        size_t fi = 0;
-        for (size_t f = 0; f < fnames.size(); f++) { // :1015-1045
+        // ---- the samples (:1015-1045).  Up to `in_flight` of them are read and classified at the same time, each by a
+        // thread with its own counters on the GPU(s): one gzip stream inflates at ~0.4 GB/s of text on one core whatever
+        // the GPU does, so a directory of samples is as fast as the cores it may use.  What a sample prints is kept and
+        // printed in directory order; a sample that fails ends the run where the reference would have ended it (the
+        // samples before it complete, what later ones wrote is removed).
+        const size_t n_samples = fnames.size(), files_per_sample = fasta_mode ? 1 : 2;
+        size_t n_workers = in_flight < 1 ? 1 : (size_t)in_flight;
+        if (n_workers > n_samples) n_workers = n_samples ? n_samples : 1;
+        struct SampleOut {
+            std::string text;
+            bool done = false, failed = false, wrote_result = false;
+            Fatal failure{0, ""};
+        };
+        std::vector<SampleOut> outs(n_samples);
+        std::mutex om;
+        std::condition_variable ocv;
+        size_t next_sample = 0;
+        bool abort_run = false;
+        std::vector<std::unique_ptr<Engine>> worker_engines;
+        for (size_t w = 1; w < n_workers; w++) worker_engines.push_back(engine_worker(eng));
+        auto process = [&](Engine &e, size_t f, std::string &out) {
             const std::string &prefix = fnames[f];
-            engine_reset(eng);
-            std::cout << prefix << std::endl;
+            const size_t fi0 = f * files_per_sample;
+            engine_reset(e);
+            out += prefix + "\n";
             long long tct = 0;
             {
                 ReadSaver saver(dname + prefix + "_reads.txt", ntar);
                 if (fasta_mode) {
-                    tct += run_file(eng, pf, fi++, saver);
-                    if (missing[f]) std::cout << "nark " << dname + prefix + e1 << std::endl;
-                    std::cout << tct << " reads loaded" << std::endl;
+                    tct += run_file(e, pf, fi0, saver);
+                    if (missing[f]) out += "nark " + dname + prefix + e1 + "\n";
+                    out += std::to_string(tct) + " reads loaded\n";
                 } else {
                     // the two mates are inflated, indexed and classified at the same time; "<tct> reads loaded" (:1030,:1036)
                     // comes when a file is through, R1 first
                     std::vector<long long> handed;
-                    run_files_together(eng, pf, fi, 2, saver, handed, [&](size_t mate) {
+                    run_files_together(e, pf, fi0, 2, saver, handed, [&](size_t mate) {
                         tct += handed[mate];
+                        std::lock_guard<std::mutex> lk(om);
                         if (t_first_file < 0) t_first_file = since_start();
-                        std::cout << tct << " reads loaded" << std::endl;
+                        out += std::to_string(tct) + " reads loaded\n";
                     });
-                    fi += 2;
                 }
             }
-            finish_sample(eng, dname + prefix + "_result.txt");
+            finish_sample(e, dname + prefix + "_result.txt");
+        };
+        auto worker = [&](Engine *e) {
+            for (;;) {
+                size_t f;
+                {
+                    std::lock_guard<std::mutex> lk(om);
+                    if (abort_run || next_sample >= n_samples) return;
+                    f = next_sample++;
+                }
+                std::string text;
+                bool failed = false;
+                Fatal failure{0, ""};
+                try { process(*e, f, text); }
+                catch (const Fatal &x) { failed = true; failure = x; }
+                std::lock_guard<std::mutex> lk(om);
+                outs[f].text = std::move(text);
+                outs[f].failed = failed;
+                outs[f].failure = failure;
+                outs[f].wrote_result = !failed;
+                outs[f].done = true;
+                if (failed) abort_run = true;
+                ocv.notify_all();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (size_t w = 1; w < n_workers; w++) pool.emplace_back(worker, worker_engines[w - 1].get());
+        std::thread first(worker, &eng);
+        int exit_code = 0;
+        std::string fail_message;
+        for (size_t f = 0; f < n_samples; f++) { // print in directory order
+            std::unique_lock<std::mutex> lk(om);
+            ocv.wait(lk, [&] { return outs[f].done || (abort_run && f >= next_sample); });
+            if (!outs[f].done) break; // never started: a sample before it failed
+            std::cout << outs[f].text << std::flush;
+            if (outs[f].failed) { exit_code = outs[f].failure.exit_code; fail_message = outs[f].failure.message; break; }
         }
+        first.join();
+        for (std::thread &t : pool) t.join();
+        if (exit_code) {
+            // samples behind the failed one that were already through: the reference never got to them
+            bool behind = false;
+            for (size_t f = 0; f < n_samples; f++) {
+                if (behind && outs[f].done) {
+                    remove((dname + fnames[f] + "_result.txt").c_str());
+                    remove((dname + fnames[f] + "_reads.txt").c_str());
+                }
+                if (outs[f].failed) behind = true;
+            }
+            throw Fatal{exit_code, fail_message};
+        }
+        const size_t fi = n_samples * files_per_sample;
+        for (const std::unique_ptr<Engine> &we : worker_engines) { eng.gpu_wait_s += we->gpu_wait_s; eng.submit_s += we->submit_s; }
         if (timing) {
             for (size_t i = 0; i < fi; i++) {
                 const SourceStats st = pf.file_stats(i);

@@ -593,12 +593,16 @@ def test_replicas_and_merged_end(seeded):
         r.close()
 
 
-def test_very_long_records_take_the_two_pass_path(seeded):
-    """FASTA contigs classified whole (kmer_read_vf6.cpp:803-861): records of more than 65536 k-mers in a host batch go
-    through kid_long_hits_kernel + kid_long_fold_kernel (every k-mer looked up by a lane of its own, one workgroup folds
-    a record's hits in position order) instead of being walked by one wave.  Same per-record results and counters as the
-    oracle's sequential fold: hits of several lineages in an order that matters, N and lower-case stretches, a start/stop
-    range, a record just above and one just below the threshold, short reads in between."""
+@pytest.mark.parametrize("entry", ["host_buffers", "device_resident", "device_resident_then_a_larger_batch"])
+def test_very_long_records_take_the_two_pass_path(seeded, entry):
+    """FASTA contigs classified whole (kmer_read_vf6.cpp:803-861): records of more than 65536 k-mers go through
+    kid_long_hits_kernel + kid_long_fold_kernel (every k-mer looked up by a lane of its own, one workgroup folds a
+    record's hits in position order) instead of being walked by one wave -- sorted out on the device (the prepare kernel
+    flags them, kid_long_plan_kernel places them), so also for batches whose offsets the host never saw.  Same
+    per-record results and counters as the oracle's sequential fold: hits of several lineages in an order that matters,
+    N and lower-case stretches, a start/stop range, a record just above and one just below the threshold, short reads in
+    between.  "then_a_larger_batch": a second batch four times as large through the same sample (the hit array, sized by
+    the first, has to grow; lists and plans of the scratch sets are reused)."""
     parent, cum, keys, targets, odb, db = seeded
     rng = np.random.default_rng(99)
     lut = np.frombuffer(b"ACGT", np.uint8)
@@ -641,12 +645,36 @@ def test_very_long_records_take_the_two_pass_path(seeded):
     eg, eu = os_.counts()
     assert len(set(exp[[0, 41, 42, 43, len(seqs) - 1]].tolist())) > 1
     s = db.sample()
-    got = s.classify(bases, off, start, stop)
+    if entry == "host_buffers":
+        got = s.classify(bases, off, start, stop)
+    else:
+        import torch
+
+        def on_device(bs, of, st_, sp_):
+            pad = np.zeros(bs.size + 64, np.uint8); pad[:bs.size] = bs
+            d_b = torch.from_numpy(pad).cuda()
+            d_o = torch.from_numpy(of.view(np.int64)).cuda()
+            d_s, d_e = torch.from_numpy(st_).cuda(), torch.from_numpy(sp_).cuda()
+            d_out = torch.full((of.size - 1,), -1, dtype=torch.int32, device="cuda")
+            s.classify_device(d_b.data_ptr(), bs.size, d_o.data_ptr(), of.size - 1, d_start=d_s.data_ptr(), d_stop=d_e.data_ptr(),
+                              d_out=d_out.data_ptr())
+            torch.cuda.synchronize()
+            return d_out.cpu().numpy().view(np.uint32)
+        got = on_device(bases, off, start, stop)
+        if entry == "device_resident_then_a_larger_batch":
+            nb = bases.size
+            b4 = np.concatenate([bases] * 4)
+            o4 = np.concatenate([off[:-1] + np.uint64(i * nb) for i in range(4)] + [np.array([4 * nb], np.uint64)])
+            got4 = on_device(b4, o4, np.tile(start, 4), np.tile(stop, 4))
+            assert np.array_equal(got4, np.tile(exp, 4))
+            os_.classify(b4, o4, np.tile(start, 4), np.tile(stop, 4))
+            eg, eu = os_.counts()
     assert np.array_equal(got, exp)
     g, u = s.end()
     assert np.array_equal(g, eg) and np.array_equal(u, eu)
     st, est = s.stats(), os_.stats()
-    assert st["lookups"] == est["lookups"] and st["hits"] == est["hits"] and st["reads"] == len(seqs)
+    assert st["lookups"] == est["lookups"] and st["hits"] == est["hits"]
+    assert st["reads"] == len(seqs) * (5 if entry == "device_resident_then_a_larger_batch" else 1)
     s.close()
 
 

@@ -1,4 +1,5 @@
-"""The C-ABI library loads and exports every symbol include/kmer_id_amd.h declares;
+"""The C-ABI library loads and exports every symbol include/kmer_id_amd.h (the boundary) and include/kmer_id_amd_bench.h
+(bench / test helpers) declare;
 host-only helpers work; compute entry points fail loudly without a GPU."""
 import os
 import re
@@ -13,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "kmer_id_amd.h")).read()
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("kmer_id_amd.h", "kmer_id_amd_bench.h"))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(kid_[a-z0-9_]+)\s*\(", text)))
 
