@@ -99,18 +99,7 @@ def build_tools(force=False, verbose=False):
     return out
 
 
-def build_oracle(verbose=False):
-    """The plain-C checker (test infrastructure) and, where the reference sources are
-    present (build container only), the compiled reference under oracle/_ref."""
-    odir = os.path.join(ROOT, "oracle")
-    subprocess.check_call(["make", "-C", odir, "oracle"] + ([] if verbose else ["-s"]))
-    if os.path.exists("/root/reference/newkmer_10nx.cpp"):
-        subprocess.check_call(["make", "-C", odir, "ref"] + ([] if verbose else ["-s"]))
-    return os.path.join(odir, "libkmer_oracle.so")
-
-
 def build_all(force=False, verbose=False):
     build_library(force=force, verbose=verbose)
     build_cli(force=force, verbose=verbose)
     build_tools(force=force, verbose=verbose)
-    build_oracle(verbose=verbose)
