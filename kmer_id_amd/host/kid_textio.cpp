@@ -9,12 +9,67 @@
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <stdlib.h>
 #include <thread>
+#include <utility>
 
 namespace kidhost {
 
 static const size_t REF_LINE_LIMIT = 0x4000; // BUFLEN, newkmer_10nx.cpp:85
 static const size_t HEAD = TextBlock::kHeadroomForLine + TextBlock::kHeadroomForRecords;
+
+// ---------------------------------------------------------------- text memory
+namespace {
+void *plain_alloc(size_t n) { return malloc(n); }
+void plain_release(void *p) { free(p); }
+struct TextPool {
+    std::mutex m;
+    void *(*alloc)(size_t) = plain_alloc;
+    void (*release)(void *) = plain_release;
+    std::vector<std::pair<char *, size_t>> spare; // let go, kept for reuse (at most 64 buffers)
+} g_pool;
+} // namespace
+
+void set_text_allocator(void *(*alloc)(size_t), void (*release)(void *))
+{
+    std::lock_guard<std::mutex> lk(g_pool.m);
+    for (auto &b : g_pool.spare) g_pool.release(b.first); // (what the old allocator gave goes back to it)
+    g_pool.spare.clear();
+    g_pool.alloc = alloc ? alloc : plain_alloc;
+    g_pool.release = release ? release : plain_release;
+}
+
+void HostBuf::resize(size_t n)
+{
+    if (n <= cap_) return;
+    reset();
+    {
+        std::lock_guard<std::mutex> lk(g_pool.m);
+        for (size_t i = 0; i < g_pool.spare.size(); i++)
+            if (g_pool.spare[i].second >= n) {
+                p_ = g_pool.spare[i].first;
+                cap_ = g_pool.spare[i].second;
+                g_pool.spare.erase(g_pool.spare.begin() + (long)i);
+                return;
+            }
+    }
+    void *p = g_pool.alloc(n);
+    if (!p) throw Fatal{1, "out of memory for a text block"};
+    p_ = (char *)p;
+    cap_ = n;
+}
+
+void HostBuf::reset()
+{
+    if (!p_) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.m);
+        if (g_pool.spare.size() < 64) { g_pool.spare.emplace_back(p_, cap_); p_ = nullptr; cap_ = 0; return; }
+    }
+    g_pool.release(p_);
+    p_ = nullptr;
+    cap_ = 0;
+}
 
 void TextBlock::prepend(const char *p, size_t n)
 {
@@ -31,7 +86,7 @@ struct GzLineBlocks::Impl {
     std::mutex m;
     std::condition_variable cv;
     std::deque<TextBlock> full;
-    std::deque<std::vector<char>> spare;
+    std::deque<HostBuf> spare;
     bool done = false, stop = false, failed = false;
     Fatal failure{0, ""};
     std::atomic<uint64_t> ns_inflate{0}, bytes{0};

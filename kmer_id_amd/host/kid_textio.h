@@ -17,10 +17,38 @@ struct Fatal {
     std::string message;
 };
 
+// Memory for file text.  Plain malloc until a front-end installs another allocator -- nk10 installs the library's
+// page-locked memory (kid_host_alloc), so that a block goes to the GPU by DMA straight from where zlib inflated it to
+// (an upload from pageable memory is first copied by the CPU, at 1.6 GB/s of the consumer thread's time).  Buffers are
+// kept for reuse when they are let go (page-locking 8 MiB takes milliseconds).
+void set_text_allocator(void *(*alloc)(size_t), void (*release)(void *));
+class HostBuf {
+public:
+    HostBuf() {}
+    ~HostBuf() { reset(); }
+    HostBuf(const HostBuf &) = delete;
+    HostBuf &operator=(const HostBuf &) = delete;
+    HostBuf(HostBuf &&o) noexcept : p_(o.p_), cap_(o.cap_) { o.p_ = nullptr; o.cap_ = 0; }
+    HostBuf &operator=(HostBuf &&o) noexcept
+    {
+        if (this != &o) { reset(); p_ = o.p_; cap_ = o.cap_; o.p_ = nullptr; o.cap_ = 0; }
+        return *this;
+    }
+    void resize(size_t n); // at least n bytes (contents are not kept)
+    void reset();          // back to the pool
+    size_t size() const { return cap_; }
+    bool empty() const { return p_ == nullptr; }
+    char *data() { return p_; }
+    const char *data() const { return p_; }
+private:
+    char *p_ = nullptr;
+    size_t cap_ = 0;
+};
+
 // A block of whole lines inside a recycled buffer.  The bytes before `off` are headroom: a consumer that carries an
 // unfinished record over from the block before copies it there (prepend) instead of copying the block.
 struct TextBlock {
-    std::vector<char> buf;
+    HostBuf buf;
     size_t off = 0, len = 0;
     const char *data() const { return buf.data() + off; }
     char *data() { return buf.data() + off; }

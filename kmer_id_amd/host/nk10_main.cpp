@@ -178,6 +178,10 @@ int main(int argc, char **argv)
             std::cout << "out of memory in table " << std::endl;
             return 1;
         }
+        // file text goes into page-locked memory from here on: uploads by DMA, not through a CPU copy
+        static int pin_device = devices[0];
+        set_text_allocator([](size_t n) -> void * { void *p = nullptr; return kid_host_alloc(pin_device, n, &p) == KID_OK ? p : nullptr; },
+                           [](void *p) { kid_host_free(p); });
         t_gpu_ready = since_start();
         tm.gpu_build_s = t_gpu_ready - t_db_loaded;
         n_devices = devices.size();
