@@ -5,7 +5,6 @@
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
-#include <zlib.h>
 
 #include <chrono>
 #include <condition_variable>
@@ -15,6 +14,7 @@
 #include <sstream>
 #include <thread>
 
+#include "kid_inflate.h"
 #include "kid_textio.h"
 
 namespace kidhost {
@@ -57,46 +57,39 @@ bool strain_list_present(const std::string &path)
 }
 
 // ---------------------------------------------------------------- gz line reader
-GzLines::GzLines(const std::string &path)
+GzLines::GzLines(const std::string &path) : gz_(new GzStream(path)) // (throws when the file cannot be opened: exit 255 like the reference's gzread(NULL))
 {
-    gz_ = gzopen(path.c_str(), "rb");
-    // gzopen failure: the reference calls gzread(NULL) -> -1 -> error(gzerror(NULL)) -> exit(255)
-    if (!gz_) throw Fatal{255, "cannot open " + path};
-    gzbuffer((gzFile)gz_, 1 << 20);
-    buf_.resize(1 << 20);
+    buf_.resize(GzStream::kWindow + (1 << 20));
 }
 
-GzLines::~GzLines()
-{
-    if (gz_) gzclose((gzFile)gz_);
-}
+GzLines::~GzLines() {}
 
 void GzLines::close()
 {
     if (gz_) {
-        int rc = gzclose((gzFile)gz_);
-        gz_ = nullptr;
-        if (rc != Z_OK) throw Fatal{255, "failed gzclose"};
+        std::unique_ptr<GzStream> gz = std::move(gz_);
+        gz->close(); // throws Fatal{255, "failed gzclose"}
     }
 }
 
+// The text sits behind GzStream::kWindow bytes of headroom: the stream writes its history in front of where it inflates
+// to -- which is the line carried over (the same bytes again) and, in front of that, the headroom.
 bool GzLines::fill()
 {
     if (eof_) return false;
+    char *text = buf_.data() + GzStream::kWindow;
     if (pos_ > 0) { // keep the partial line at the front
-        memmove(buf_.data(), buf_.data() + pos_, end_ - pos_);
+        memmove(text, text + pos_, end_ - pos_);
         end_ -= pos_;
         pos_ = 0;
     }
-    if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);
-    int got = gzread((gzFile)gz_, buf_.data() + end_, (unsigned)(buf_.size() - end_));
-    if (got < 0) {
-        int err = 0;
-        const char *msg = gzerror((gzFile)gz_, &err);
-        throw Fatal{255, msg ? msg : "gzread failed"};
+    if (buf_.size() - GzStream::kWindow - end_ < GzStream::kMinRead) {
+        buf_.resize(buf_.size() * 2);
+        text = buf_.data() + GzStream::kWindow;
     }
+    const size_t got = gz_->read((uint8_t *)text + end_, buf_.size() - GzStream::kWindow - end_);
     if (got == 0) { eof_ = true; return false; }
-    end_ += (size_t)got;
+    end_ += got;
     return true;
 }
 
@@ -104,7 +97,7 @@ bool GzLines::next(const char *&line, size_t &len)
 {
     size_t scanned = 0;
     for (;;) {
-        const char *base = buf_.data() + pos_;
+        const char *base = buf_.data() + GzStream::kWindow + pos_;
         const char *nl = (const char *)memchr(base + scanned, '\n', end_ - pos_ - scanned);
         if (nl) {
             size_t l = (size_t)(nl - base);

@@ -10,6 +10,7 @@
 #include <utility>
 #include <vector>
 
+#include "kid_inflate.h"
 #include "kid_textio.h"
 #include "kmer_id_amd.h"
 
@@ -75,7 +76,7 @@ struct ProbeSet {
 };
 // Wall-clock seconds of the start-up phases, for --timing (nk10 prints them to stderr as one JSON line)
 struct StartupTiming {
-    double inflate_s = 0;      // inside gzread (the inflate thread; overlaps the parse)
+    double inflate_s = 0;      // inside GzStream::read (the inflate thread; overlaps the parse)
     double parse_wall_s = 0;   // probes text -> keys: inflate + parse workers, wall
     double cache_read_s = 0, cache_write_s = 0;
     double gpu_build_s = 0;    // kid_db_build: upload + table build on the GPU
@@ -110,7 +111,7 @@ public:
     bool next(const char *&line, size_t &len); // false at end of file
     void close();                               // throws Fatal{255} "failed gzclose"
 private:
-    void *gz_ = nullptr;
+    std::unique_ptr<GzStream> gz_;
     std::vector<char> buf_;
     size_t pos_ = 0, end_ = 0;
     bool eof_ = false;
@@ -139,7 +140,7 @@ struct ReadBatch {
 // A file of reads delivered as batches.  fill() clears `out`, appends reads until max_reads reads or
 // max_bases bases are in it, and returns false when the file is exhausted and nothing was appended.
 struct SourceStats { // seconds a file's host stages took (--timing)
-    double inflate_s = 0; // inside gzread (its own thread)
+    double inflate_s = 0; // inside GzStream::read (its own thread)
     double index_s = 0;   // finding lines / parsing / trimming (the reader thread)
     uint64_t text_bytes = 0;
 };

@@ -1,8 +1,9 @@
 // kid_textio.cpp -- see kid_textio.h
 #include "kid_textio.h"
 
+#include "kid_inflate.h"
+
 #include <string.h>
-#include <zlib.h>
 
 #include <atomic>
 #include <chrono>
@@ -80,7 +81,7 @@ void TextBlock::prepend(const char *p, size_t n)
 }
 
 struct GzLineBlocks::Impl {
-    gzFile gz = nullptr;
+    std::unique_ptr<GzStream> gz;
     size_t chunk_bytes, depth;
     std::thread th;
     std::mutex m;
@@ -113,14 +114,14 @@ struct GzLineBlocks::Impl {
             }
             if (b.buf.size() < HEAD + chunk_bytes) b.buf.resize(HEAD + chunk_bytes);
             const auto t0 = std::chrono::steady_clock::now();
-            const int got = gzread(gz, b.buf.data() + HEAD, (unsigned)chunk_bytes);
-            ns_inflate += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-            if (got < 0) {
-                int err = 0;
-                const char *msg = gzerror(gz, &err);
-                fail(Fatal{255, msg ? msg : "gzread failed"});
+            size_t got = 0;
+            try {
+                got = gz->read((uint8_t *)b.buf.data() + HEAD, chunk_bytes); // (HEAD >= GzStream::kWindow: the stream's history goes in front)
+            } catch (const Fatal &f) {
+                fail(f);
                 return;
             }
+            ns_inflate += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
             if (got == 0) { // end of file: the unterminated tail is dropped (:812-813) -- unless the reference's buffer had overflowed on it first
                 if (carry.size() >= REF_LINE_LIMIT) { fail(Fatal{255, "Buffer to small for input line lengths"}); return; }
                 std::lock_guard<std::mutex> lk(m);
@@ -157,10 +158,7 @@ struct GzLineBlocks::Impl {
 
 GzLineBlocks::GzLineBlocks(const std::string &path, size_t block_bytes, size_t depth) : impl_(new Impl())
 {
-    impl_->gz = gzopen(path.c_str(), "rb");
-    // gzopen failure: the reference calls gzread(NULL) -> -1 -> error(gzerror(NULL)) -> exit(255)
-    if (!impl_->gz) throw Fatal{255, "cannot open " + path};
-    gzbuffer(impl_->gz, 1 << 20);
+    impl_->gz.reset(new GzStream(path)); // (throws when the file cannot be opened: exit 255 like the reference's gzread(NULL))
     impl_->chunk_bytes = block_bytes < 2 * REF_LINE_LIMIT ? 2 * REF_LINE_LIMIT : block_bytes;
     impl_->depth = depth < 1 ? 1 : depth;
     impl_->th = std::thread([this] { impl_->run(); });
@@ -174,7 +172,6 @@ GzLineBlocks::~GzLineBlocks()
         impl_->cv.notify_all();
     }
     if (impl_->th.joinable()) impl_->th.join();
-    if (impl_->gz) gzclose(impl_->gz);
 }
 
 bool GzLineBlocks::next(TextBlock &b)
@@ -209,9 +206,8 @@ void GzLineBlocks::close()
     }
     if (impl_->th.joinable()) impl_->th.join();
     if (impl_->gz) {
-        const int rc = gzclose(impl_->gz);
-        impl_->gz = nullptr;
-        if (rc != Z_OK) throw Fatal{255, "failed gzclose"};
+        std::unique_ptr<GzStream> gz = std::move(impl_->gz);
+        gz->close(); // throws Fatal{255, "failed gzclose"} for a file that ended inside a stream
     }
 }
 

@@ -1,6 +1,6 @@
-// kid_textio.h -- gzip text input as a pipeline: one thread inflates and cuts the text into blocks of whole lines, the
-// consumers work on the blocks in parallel (probes file: parse workers; FASTQ: the record indexer).  zlib inflates a
-// stream at 0.2-0.5 GB/s of text on one core and cannot be split; everything behind it can.
+// kid_textio.h -- gzip text input as a pipeline: one thread inflates (kid_inflate.h) and cuts the text into blocks of
+// whole lines, the consumers work on the blocks in parallel (probes file: parse workers; FASTQ: the record indexer).
+// A gzip stream cannot be split, so the inflate thread is the pace of a file; everything behind it can be spread out.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -18,7 +18,7 @@ struct Fatal {
 };
 
 // Memory for file text.  Plain malloc until a front-end installs another allocator -- nk10 installs the library's
-// page-locked memory (kid_host_alloc), so that a block goes to the GPU by DMA straight from where zlib inflated it to
+// page-locked memory (kid_host_alloc), so that a block goes to the GPU by DMA straight from where it was inflated to
 // (an upload from pageable memory is first copied by the CPU, at 1.6 GB/s of the consumer thread's time).  Buffers are
 // kept for reuse when they are let go (page-locking 8 MiB takes milliseconds).
 void set_text_allocator(void *(*alloc)(size_t), void (*release)(void *));
@@ -58,7 +58,7 @@ struct TextBlock {
     static const size_t kHeadroomForRecords = 4 * 0x4000; // a consumer's carry: up to three lines of an unfinished record
 };
 
-// A thread that inflates one .gz file (or reads a plain file: gzread passes those through) and hands out its text in
+// A thread that inflates one .gz file (or reads a plain file: like gzread, GzStream passes those through) and hands out its text in
 // blocks that end with a '\n'.  The rules of the reference's reader (newkmer_10nx.cpp:762-816) that concern raw text:
 // a line of 16384 bytes or more is fatal (exit 255, :773), the unterminated tail of the file is dropped (:812-813).
 // Failures surface in stream order: next() throws Fatal{255} where the reference's gzread loop would have called
@@ -73,7 +73,7 @@ public:
     bool next(TextBlock &b);
     void recycle(TextBlock &b);      // give a buffer back without asking for the next block
     void close();                    // gzclose; throws Fatal{255} "failed gzclose"
-    double inflate_seconds() const;  // time spent inside gzread so far
+    double inflate_seconds() const;  // time spent inflating so far
     uint64_t bytes_out() const;
 private:
     struct Impl;

@@ -1,0 +1,64 @@
+// kid_gzcat -- test tool: the text of a .gz file on stdout, read either by the host code's own inflate loop
+// (kmer_id_amd/host/kid_inflate.cpp) or, with --zlib, by zlib's gzread the way the reference reads its files
+// (newkmer_10nx.cpp:762-816: 16 KiB calls).  tests/test_host_inflate.py compares the two on good, odd and damaged files.
+//   kid_gzcat [--zlib] [--room BYTES] FILE
+// exit 0 = read to the end and closed; 3 = a read failed (message on stderr); 4 = the close failed ("failed gzclose").
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <string>
+#include <vector>
+
+#include "../kmer_id_amd/host/kid_inflate.h"
+#include "../kmer_id_amd/host/kid_textio.h"
+
+int main(int argc, char **argv)
+{
+    bool use_zlib = false;
+    size_t room = (size_t)1 << 20;
+    const char *path = nullptr;
+    for (int i = 1; i < argc; i++) {
+        if (!strcmp(argv[i], "--zlib")) use_zlib = true;
+        else if (!strcmp(argv[i], "--room") && i + 1 < argc) room = (size_t)atol(argv[++i]);
+        else path = argv[i];
+    }
+    if (!path) return 2;
+    if (use_zlib) {
+        gzFile g = gzopen(path, "rb");
+        if (!g) { fprintf(stderr, "cannot open\n"); return 3; }
+        std::vector<char> buf(0x4000);
+        for (;;) {
+            const int n = gzread(g, buf.data(), (unsigned)buf.size());
+            if (n == 0) break;
+            if (n < 0) {
+                int err = 0;
+                fprintf(stderr, "%s\n", gzerror(g, &err));
+                return 3;
+            }
+            fwrite(buf.data(), 1, (size_t)n, stdout);
+        }
+        if (gzclose(g) != Z_OK) { fprintf(stderr, "failed gzclose\n"); return 4; }
+        return 0;
+    }
+    try {
+        kidhost::GzStream z(path);
+        std::vector<uint8_t> buf(kidhost::GzStream::kWindow + room);
+        try {
+            for (;;) {
+                const size_t n = z.read(buf.data() + kidhost::GzStream::kWindow, room);
+                if (n == 0) break;
+                fwrite(buf.data() + kidhost::GzStream::kWindow, 1, n, stdout);
+            }
+        } catch (const kidhost::Fatal &f) {
+            fprintf(stderr, "%s\n", f.message.c_str());
+            return 3;
+        }
+        z.close();
+    } catch (const kidhost::Fatal &f) {
+        fprintf(stderr, "%s\n", f.message.c_str());
+        return 4;
+    }
+    return 0;
+}
