@@ -225,14 +225,14 @@ def cli_e2e_leg(threads):
         base = min(run(empty)[0] for _ in range(2))
         out = {"startup_s": base, "reader_threads": threads, "pairs_per_sample": P,
                "what": "nk10 <dir> on 1 and on 2 samples x %d pairs of 150 bp FASTQ.gz (mixed qualities; process_qual and "
-                       "classification on the GPU), wall minus the program's startup on an empty directory; bounded by zlib "
-                       "inflate: one stream per file, the two mates of a sample at the same time" % P}
+                       "classification on the GPU), wall minus the program's startup on an empty directory; bounded by the "
+                       "inflate thread: one stream per file, the two mates of a sample at the same time" % P}
         for name, (d, S) in dirs.items():
             wall, tm = run(d)
             g = sum(int(line.split(",")[1]) for line in open(d + "S0_result.txt"))
             out[name] = {"pairs_per_s": S * P / max(wall - base, 1e-6), "wall_s": wall, "reads_counted_sample0": g,
                          "stages": None if tm is None else {k_: tm[k_] for k_ in ("consumer_waited_for_host_stages_s", "consumer_waited_for_gpu_s",
-                                                                                  "consumer_submit_s", "files") if k_ in tm}}
+                                                                                  "consumer_submit_s", "gpu_ready_at_s", "total_s", "files", "samples") if k_ in tm}}
         out["pairs_per_s"] = out["two_samples"]["pairs_per_s"]
         return out
     finally:

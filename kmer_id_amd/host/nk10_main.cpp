@@ -107,6 +107,7 @@ int main(int argc, char **argv)
         double t_gpu_ready = -1, t_first_file = -1;
         size_t n_entries = ps.keys.size(), n_devices = 0;
         std::string files_json; // per read file: seconds of its host stages
+        std::string samples_json; // per sample: when it began, when its files were through, when its outputs were written
         double host_wait_s = 0, gpu_wait_s = 0, submit_s = 0;
         auto print_timing = [&]() {
             if (!timing) return;
@@ -115,10 +116,10 @@ int main(int argc, char **argv)
                             "\"db_loaded_at_s\": %.3f, \"gpu_upload_and_build_s\": %.3f, \"gpu_ready_at_s\": %.3f, "
                             "\"first_file_classified_at_s\": %.3f, \"total_s\": %.3f, \"log2_slots\": %d, \"devices\": %zu, "
                             "\"consumer_waited_for_host_stages_s\": %.3f, \"consumer_waited_for_gpu_s\": %.3f, \"consumer_submit_s\": %.3f, "
-                            "\"reader_threads\": %d, \"samples_in_flight\": %d, \"files\": [%s]}}\n",
+                            "\"reader_threads\": %d, \"samples_in_flight\": %d, \"files\": [%s], \"samples\": [%s]}}\n",
                     n_entries, from_cache ? "true" : "false", (unsigned long long)tm.text_bytes, tm.inflate_s, tm.parse_wall_s,
                     tm.parse_threads, tm.cache_read_s, tm.cache_write_s, t_db_loaded, tm.gpu_build_s, t_gpu_ready, t_first_file,
-                    since_start(), log2_slots, n_devices, host_wait_s, gpu_wait_s, submit_s, threads, in_flight, files_json.c_str());
+                    since_start(), log2_slots, n_devices, host_wait_s, gpu_wait_s, submit_s, threads, in_flight, files_json.c_str(), samples_json.c_str());
         };
         std::cout << "tree loaded" << std::endl;
         std::cout << ps.lines_parsed << " kmers loaded" << std::endl;
@@ -247,6 +248,8 @@ int main(int argc, char **argv)
         auto process = [&](Engine &e, size_t f, std::string &out) {
             const std::string &prefix = fnames[f];
             const size_t fi0 = f * files_per_sample;
+            const double t_begin = since_start();
+            double t_file_done[2] = {-1, -1};
             engine_reset(e);
             out += prefix + "\n";
             long long tct = 0;
@@ -264,11 +267,20 @@ int main(int argc, char **argv)
                         tct += handed[mate];
                         std::lock_guard<std::mutex> lk(om);
                         if (t_first_file < 0) t_first_file = since_start();
+                        t_file_done[mate] = since_start();
                         out += std::to_string(tct) + " reads loaded\n";
                     });
                 }
             }
+            const double t_reads_written = since_start();
             finish_sample(e, dname + prefix + "_result.txt");
+            if (timing) {
+                char buf[256];
+                snprintf(buf, sizeof(buf), "{\"sample\": %zu, \"begin_s\": %.3f, \"r1_through_s\": %.3f, \"r2_through_s\": %.3f, \"reads_txt_written_s\": %.3f, "
+                                           "\"result_written_s\": %.3f}", f, t_begin, t_file_done[0], t_file_done[1], t_reads_written, since_start());
+                std::lock_guard<std::mutex> lk(om);
+                samples_json += (samples_json.empty() ? "" : ", ") + std::string(buf);
+            }
         };
         auto worker = [&](Engine *e) {
             for (;;) {

@@ -1,13 +1,14 @@
 // kid_gzcat -- test tool: the text of a .gz file on stdout, read either by the host code's own inflate loop
 // (kmer_id_amd/host/kid_inflate.cpp) or, with --zlib, by zlib's gzread the way the reference reads its files
 // (newkmer_10nx.cpp:762-816: 16 KiB calls).  tests/test_host_inflate.py compares the two on good, odd and damaged files.
-//   kid_gzcat [--zlib] [--room BYTES] FILE
+//   kid_gzcat [--zlib] [--room BYTES] [--time] FILE      (--time: no text; the best of three passes, as MB/s of text)
 // exit 0 = read to the end and closed; 3 = a read failed (message on stderr); 4 = the close failed ("failed gzclose").
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -16,15 +17,47 @@
 
 int main(int argc, char **argv)
 {
-    bool use_zlib = false;
+    bool use_zlib = false, time_it = false;
     size_t room = (size_t)1 << 20;
     const char *path = nullptr;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--zlib")) use_zlib = true;
+        else if (!strcmp(argv[i], "--time")) time_it = true;
         else if (!strcmp(argv[i], "--room") && i + 1 < argc) room = (size_t)atol(argv[++i]);
         else path = argv[i];
     }
     if (!path) return 2;
+    if (time_it) {
+        double best = 1e30;
+        size_t total = 0;
+        for (int pass = 0; pass < 3; pass++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            total = 0;
+            if (use_zlib) {
+                gzFile g = gzopen(path, "rb");
+                if (!g) return 3;
+                gzbuffer(g, 1 << 20);
+                std::vector<char> buf(room);
+                int n;
+                while ((n = gzread(g, buf.data(), (unsigned)buf.size())) > 0) total += (size_t)n;
+                gzclose(g);
+            } else {
+                try {
+                    kidhost::GzStream z(path);
+                    std::vector<uint8_t> buf(kidhost::GzStream::kWindow + room);
+                    size_t n;
+                    while ((n = z.read(buf.data() + kidhost::GzStream::kWindow, room)) > 0) total += n;
+                } catch (const kidhost::Fatal &f) {
+                    fprintf(stderr, "%s\n", f.message.c_str());
+                    return 3;
+                }
+            }
+            const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (t < best) best = t;
+        }
+        printf("%s %s: %zu bytes of text, %.3f s, %.1f MB/s\n", use_zlib ? "zlib" : "kid ", path, total, best, (double)total / best / 1e6);
+        return 0;
+    }
     if (use_zlib) {
         gzFile g = gzopen(path, "rb");
         if (!g) { fprintf(stderr, "cannot open\n"); return 3; }
