@@ -1,6 +1,8 @@
 #include "kid_driver.h"
 
+#include <stdio.h>
 #include <stdlib.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <condition_variable>
@@ -10,6 +12,14 @@
 #include <thread>
 
 namespace kidhost {
+
+void leave_now(int exit_code)
+{
+    std::cout.flush();
+    std::cerr.flush();
+    fflush(nullptr);
+    _exit(exit_code);
+}
 
 void die_kid(int rc)
 {

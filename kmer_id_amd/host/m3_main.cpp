@@ -149,6 +149,7 @@ int main(int argc, char **argv)
             std::cout << tct << " reads loaded" << std::endl;
         }
         finish_sample(eng, wdir + "result.txt");
+        leave_now(0);
     } catch (const Fatal &f) {
         std::cerr << f.message << "\n";
         return f.exit_code;

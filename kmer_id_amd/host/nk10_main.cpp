@@ -346,6 +346,7 @@ int main(int argc, char **argv)
             submit_s = eng.submit_s;
         }
         print_timing();
+        leave_now(0);
     } catch (const Fatal &f) {
         std::cerr << f.message << "\n";
         return f.exit_code;

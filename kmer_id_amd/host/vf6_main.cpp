@@ -154,6 +154,7 @@ int main(int argc, char **argv)
             std::cout << tct << " reads loaded" << std::endl;
             finish_sample(eng, base + "_result.txt");
         }
+        leave_now(0);
     } catch (const Fatal &f) {
         std::cerr << f.message << "\n";
         return f.exit_code;
