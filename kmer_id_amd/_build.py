@@ -97,9 +97,10 @@ def build_tools(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     # kid_gzcat: the host code's gzip reader beside zlib's (tests/test_host_inflate.py)
-    gsrc = [os.path.join(ROOT, "tools", "kid_gzcat.cpp"), os.path.join(HOST, "kid_inflate.cpp"), os.path.join(HOST, "kid_textio.cpp")]
+    gsrc = [os.path.join(ROOT, "tools", "kid_gzcat.cpp"), os.path.join(HOST, "kid_inflate.cpp"), os.path.join(HOST, "kid_pargz.cpp"),
+            os.path.join(HOST, "kid_textio.cpp")]
     gout = os.path.join(BIN_DIR, "kid_gzcat")
-    if all(os.path.exists(s) for s in gsrc) and (force or _newer(gout, gsrc + [os.path.join(HOST, "kid_inflate.h"), os.path.join(HOST, "kid_textio.h")])):
+    if all(os.path.exists(s) for s in gsrc) and (force or _newer(gout, gsrc + [os.path.join(HOST, h) for h in ("kid_inflate.h", "kid_inflate_internal.h", "kid_pargz.h", "kid_textio.h")])):
         cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-Wall", "-o", gout] + gsrc + ["-lz", "-lpthread"]
         if verbose:
             print(" ".join(cmd))

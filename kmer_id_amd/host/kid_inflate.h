@@ -21,12 +21,31 @@
 
 namespace kidhost {
 
+// Where a stream goes on in the middle of a gzip member (kid_pargz.h: the piece of a file that is not inflated in
+// parallel): at the block header at `bit_offset` of the file, with the member's text so far as history and in its sums.
+struct GzResume {
+    uint64_t bit_offset;
+    const uint8_t *window; // the last window_len bytes of text in front (window_len <= 32768)
+    size_t window_len;
+    uint32_t crc;          // CRC-32 of the member's text so far
+    uint64_t member_out;   // its length
+};
+
 class GzStream {
 public:
     static const size_t kWindow = 32768; // bytes in FRONT of a read()'s destination that the stream may write to
     static const size_t kMinRead = 4096; // smallest `cap` read() takes
     // throws Fatal{255} when the file cannot be opened (the reference: gzread(NULL) -> -1 -> exit 255)
     explicit GzStream(const std::string &path);
+    GzStream(const std::string &path, const GzResume &from);
+    // read() comes back early, in front of the first block header at or behind `byte_offset` of the file that announces
+    // a dynamic-code block (the kind a parallel reader can find from the outside); stopped() says so, and where.
+    void stop_at_dynamic_block_from(uint64_t byte_offset);
+    bool stopped() const;
+    uint64_t stopped_at_bit() const;
+    uint32_t member_crc() const;      // of the current member's text handed out so far
+    uint64_t member_length() const;
+    size_t history(uint8_t *dst) const; // the last (up to kWindow) bytes of the current member's text; returns how many
     ~GzStream();
     GzStream(const GzStream &) = delete;
     GzStream &operator=(const GzStream &) = delete;

@@ -2,6 +2,7 @@
 #include "kid_textio.h"
 
 #include "kid_inflate.h"
+#include "kid_pargz.h"
 
 #include <string.h>
 
@@ -80,8 +81,13 @@ void TextBlock::prepend(const char *p, size_t n)
     memcpy(buf.data() + off, p, n);
 }
 
+static std::atomic<int> g_inflate_threads{1};
+void set_inflate_threads(int n) { g_inflate_threads = n < 1 ? 1 : n; }
+
 struct GzLineBlocks::Impl {
     std::unique_ptr<GzStream> gz;
+    std::unique_ptr<ParallelGz> par;
+    uint64_t par_bytes = 0;
     size_t chunk_bytes, depth;
     std::thread th;
     std::mutex m;
@@ -112,11 +118,15 @@ struct GzLineBlocks::Impl {
                 if (stop) return;
                 if (!spare.empty()) { b.buf = std::move(spare.front()); spare.pop_front(); }
             }
-            if (b.buf.size() < HEAD + chunk_bytes) b.buf.resize(HEAD + chunk_bytes);
+            if (!par && b.buf.size() < HEAD + chunk_bytes) b.buf.resize(HEAD + chunk_bytes);
             const auto t0 = std::chrono::steady_clock::now();
             size_t got = 0;
             try {
-                got = gz->read((uint8_t *)b.buf.data() + HEAD, chunk_bytes); // (HEAD >= GzStream::kWindow: the stream's history goes in front)
+                if (par) {
+                    if (!par->next(b.buf, got)) got = 0;
+                } else {
+                    got = gz->read((uint8_t *)b.buf.data() + HEAD, chunk_bytes); // (HEAD >= GzStream::kWindow: the stream's history goes in front)
+                }
             } catch (const Fatal &f) {
                 fail(f);
                 return;
@@ -156,10 +166,13 @@ struct GzLineBlocks::Impl {
     }
 };
 
-GzLineBlocks::GzLineBlocks(const std::string &path, size_t block_bytes, size_t depth) : impl_(new Impl())
+GzLineBlocks::GzLineBlocks(const std::string &path, size_t block_bytes, size_t depth, int inflate_threads) : impl_(new Impl())
 {
-    impl_->gz.reset(new GzStream(path)); // (throws when the file cannot be opened: exit 255 like the reference's gzread(NULL))
     impl_->chunk_bytes = block_bytes < 2 * REF_LINE_LIMIT ? 2 * REF_LINE_LIMIT : block_bytes;
+    const int nt = inflate_threads > 0 ? inflate_threads : g_inflate_threads.load();
+    // (both throw when the file cannot be opened: exit 255 like the reference's gzread(NULL))
+    if (nt > 1) impl_->par.reset(new ParallelGz(path, nt, (size_t)2 << 20, impl_->chunk_bytes, HEAD));
+    else impl_->gz.reset(new GzStream(path));
     impl_->depth = depth < 1 ? 1 : depth;
     impl_->th = std::thread([this] { impl_->run(); });
 }
@@ -209,9 +222,15 @@ void GzLineBlocks::close()
         std::unique_ptr<GzStream> gz = std::move(impl_->gz);
         gz->close(); // throws Fatal{255, "failed gzclose"} for a file that ended inside a stream
     }
+    if (impl_->par) {
+        std::unique_ptr<ParallelGz> par = std::move(impl_->par);
+        impl_->par_bytes = par->bytes_in_parallel();
+        par->close();
+    }
 }
 
 double GzLineBlocks::inflate_seconds() const { return (double)impl_->ns_inflate.load() * 1e-9; }
 uint64_t GzLineBlocks::bytes_out() const { return impl_->bytes.load(); }
+uint64_t GzLineBlocks::bytes_inflated_in_parallel() const { return impl_->par ? impl_->par->bytes_in_parallel() : impl_->par_bytes; }
 
 } // namespace kidhost

@@ -63,9 +63,12 @@ struct TextBlock {
 // a line of 16384 bytes or more is fatal (exit 255, :773), the unterminated tail of the file is dropped (:812-813).
 // Failures surface in stream order: next() throws Fatal{255} where the reference's gzread loop would have called
 // error() (:87-91, :772-778), after every block before the failure has been handed out.
+// inflate_threads: 0 = what set_inflate_threads() said (1 until a front-end says otherwise); 1 = the one inflate thread
+// does it all; more = that many helpers inflate pieces of the file side by side (kid_pargz.h), same text, same failures.
+void set_inflate_threads(int n);
 class GzLineBlocks {
 public:
-    explicit GzLineBlocks(const std::string &path, size_t block_bytes = (size_t)8 << 20, size_t depth = 4);
+    explicit GzLineBlocks(const std::string &path, size_t block_bytes = (size_t)8 << 20, size_t depth = 4, int inflate_threads = 0);
     ~GzLineBlocks();
     GzLineBlocks(const GzLineBlocks &) = delete;
     GzLineBlocks &operator=(const GzLineBlocks &) = delete;
@@ -75,6 +78,7 @@ public:
     void close();                    // gzclose; throws Fatal{255} "failed gzclose"
     double inflate_seconds() const;  // time spent inflating so far
     uint64_t bytes_out() const;
+    uint64_t bytes_inflated_in_parallel() const;
 private:
     struct Impl;
     std::unique_ptr<Impl> impl_;

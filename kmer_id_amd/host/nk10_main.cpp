@@ -80,6 +80,8 @@ int main(int argc, char **argv)
     if (!db_dir.empty() && db_dir.back() != '/') db_dir += "/";
     if (batch_reads < 1) batch_reads = 1;
     if (threads < 1) threads = 1;
+    // the probes file: half of the threads inflate pieces of it side by side, the others parse (fewer than three: one inflates it all)
+    set_inflate_threads(threads / 2 >= 3 ? threads / 2 : 1);
     if (in_flight <= 0) in_flight = threads / 2 > 0 ? threads / 2 : 1; // (a sample = two files = two inflate threads)
 
     try {
@@ -224,10 +226,17 @@ int main(int argc, char **argv)
                 files.push_back([path, k]() { return std::unique_ptr<ReadSource>(new FastqStream(path, k)); });
             }
         }
+        {   // the threads are shared out over the files that are read at the same time (before the first file is opened)
+            const size_t fps = fasta_mode ? 1 : 2;
+            size_t at_once = in_flight < 1 ? 1 : (size_t)in_flight;
+            if (at_once > fnames.size()) at_once = fnames.empty() ? 1 : fnames.size();
+            const size_t per_file = (size_t)threads / (fps * at_once);
+            set_inflate_threads(per_file >= 3 ? (int)per_file : 1);
+        }
         Prefetcher pf(std::move(files), threads, eng.batch_reads, eng.batch_bases);
         // ---- the samples (:1015-1045).  Up to `in_flight` of them are read and classified at the same time, each by a
-        // thread with its own counters on the GPU(s): one gzip stream inflates at ~0.4 GB/s of text on one core whatever
-        // the GPU does, so a directory of samples is as fast as the cores it may use.  What a sample prints is kept and
+        // thread with its own counters on the GPU(s): the host's work per file (inflate, find the lines) is what a sample
+        // waits for, so a directory of samples is as fast as the cores it may use.  What a sample prints is kept and
         // printed in directory order; a sample that fails ends the run where the reference would have ended it (the
         // samples before it complete, what later ones wrote is removed).
         const size_t n_samples = fnames.size(), files_per_sample = fasta_mode ? 1 : 2;

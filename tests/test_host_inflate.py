@@ -4,7 +4,9 @@ for every kind of deflate block and gzip member layout; and for files that are c
 caller of gzread observes: a read error with zlib's message after the text in front of the damage (exit 255 in the
 reference, :776), or -- for a file that ends inside a stream -- all the text, end of file, and a failing gzclose (:815).
 
-tools/kid_gzcat.cpp prints a file's text with either reader; exit 0 = fine, 3 = read error, 4 = close failed."""
+tools/kid_gzcat.cpp prints a file's text with either reader; exit 0 = fine, 3 = read error, 4 = close failed.
+Every file also goes through the parallel reader (kmer_id_amd/host/kid_pargz.cpp: block headers found from the outside,
+pieces inflated into symbols, windows resolved afterwards) with small pieces, so that each file is cut many times."""
 import gzip
 import os
 import struct
@@ -47,6 +49,12 @@ def same_as_zlib(gzcat, path, rooms=(1 << 20,), cut_off=False):
             assert out[:len(out_z)] == out_z and err == err_z, (path, room, err, err_z, len(out), len(out_z))
         else:
             assert out == out_z and err == err_z, (path, room, err, err_z, len(out), len(out_z))
+    # pieces of the file inflated side by side (kid_pargz.cpp): the sequential reader's text and failures, byte for byte
+    rc, out, err = run(gzcat, path, "--room", "70000")
+    for threads, chunk in ((3, 4096), (2, 30000), (4, 1 << 20)):
+        rc_p, out_p, err_p = run(gzcat, path, "--threads", str(threads), "--chunk", str(chunk), "--room", "70000")
+        err_p = "\n".join(l for l in err_p.splitlines() if not l.startswith("parallel: "))
+        assert (rc_p, err_p) == (rc, err) and out_p == out, (path, threads, chunk, rc_p, rc, err_p, err, len(out_p), len(out))
     return rc_z, out_z, err_z
 
 
@@ -80,6 +88,9 @@ def texts():
         "period3": b"abc" * 50000, "period7": b"0123456" * 30000, "period9": b"012345678" * 30000,  # overlapping copies
         "far": (bytes(rng.integers(0, 256, 32768).astype(np.uint8)) * 4),   # matches at the far end of the window
         "empty": b"",
+        # every kind of block in one stream, several times over
+        "mixed": b"".join(fastq[i * 150000:(i + 1) * 150000] + bytes(rng.integers(0, 256, 40000).astype(np.uint8)) +
+                          probes[i * 150000:(i + 1) * 150000] + bytes(70000) + b"xyz" * 10 for i in range(4)),
     }
 
 
@@ -139,7 +150,7 @@ def test_cut_off_files_end_quietly_and_fail_at_close(gzcat, tmp_path):
         rc, _, _ = same_as_zlib(gzcat, p, rooms=(4096,), cut_off=True)
         assert rc in (0, 4)                      # (0: the one-byte file is "plain text")
     rng = np.random.default_rng(5)
-    for name in ("fastq", "noise", "zeros", "period7"):
+    for name in ("fastq", "noise", "zeros", "period7", "mixed"):
         for kw in (dict(level=1), dict(level=6), dict(strategy=zlib.Z_FIXED)):
             blob = member(t[name], **kw) + member(t["probes"][:5000])
             for n in sorted(set(rng.integers(1, len(blob), 12).tolist() + [len(blob) - 1, len(blob) - 8, len(blob) - 9])):
@@ -154,7 +165,7 @@ def test_damaged_streams_fail_like_zlib(gzcat, tmp_path):
     p = str(tmp_path / "flip.gz")
     seen = {}
     for name, kw in (("fastq", dict(level=6)), ("fastq", dict(level=1)), ("probes", dict(level=6)), ("probes", dict(strategy=zlib.Z_FIXED)),
-                     ("noise", dict(level=6)), ("period7", dict(level=6))):
+                     ("noise", dict(level=6)), ("period7", dict(level=6)), ("mixed", dict(level=6)), ("mixed", dict(level=1))):
         blob = bytearray(member(t[name], **kw))
         for _ in range(40):
             at = int(rng.integers(10, len(blob)))
