@@ -3,12 +3,15 @@
 // and paired FASTQ.gz files named like newkmer_10nx.cpp:29-30 wants them.  The real probes10.txt.gz is not
 // distributed with the reference (README.md:12); this is how a full-scale stand-in (108 585 519 lines, ~5.4 GB of
 // text) is made in seconds: the generators are the library's own (kid_common.h: kid_synth_db_key, kid_synth_read),
-// blocks of lines are deflated on all cores and written as consecutive gzip members -- a valid .gz that zlib's
-// gzread (what the reference uses, newkmer_10nx.cpp:673) reads as one stream.
+// blocks of lines are deflated on all cores and written the way pigz does it: ONE gzip member, every block's deflate
+// data ended on a byte boundary (Z_SYNC_FLUSH) and appended, the last one finished, the CRC-32s combined -- the kind of
+// file `gzip` itself writes, which zlib's gzread (what the reference uses, newkmer_10nx.cpp:673) reads as one stream.
+// (--members: every block a gzip member of its own, the way bgzip-like writers do it.)
 //
 //   kid_synth_files probes --counts FILE --out FILE.gz [--scale S] [--k 30] [--seed N] [--threads T] [--level L]
 //   kid_synth_files fastq  --counts FILE --tree FILE --out-dir DIR/ --samples S --pairs P [--read-len 150]
 //                          [--qual mixed|high] [--r0 N] [--prefix S] [--threads T] [--level L] [--scale S] [--k 30]
+//   both: [--members]
 // FILE formats: --counts: one line per target "target,kmers" (what b10/refkey10.txt holds in columns 1 and 3);
 //               --tree: "parent child" per line (b10/btree_10.txt).
 // FASTQ records have a fixed width ("@r%09llu/%d"), so that a test can map a file back to arrays without parsing.
@@ -36,18 +39,22 @@ static const uint64_t DB_SEED = 0xB10, READ_SEED = 0x5EED, QUAL_SEED = 0x9A1; //
     exit(2);
 }
 
-// ---------------------------------------------------------------- ordered, parallel gzip-member writer
-// make(c, text) fills the text of chunk c; workers deflate it and append the members to the file in chunk order.
+// ---------------------------------------------------------------- ordered, parallel gzip writer
+// make(c, text) fills the text of chunk c; workers deflate it and append the pieces to the file in chunk order.
+static bool g_members = false;
 static void write_gz_chunks(const std::string &path, uint64_t n_chunks, int threads, int level,
                             const std::function<void(uint64_t, std::string &)> &make)
 {
     if (n_chunks == 0) n_chunks = 1; // (an empty text still makes a valid gzip member)
     FILE *f = fopen(path.c_str(), "wb");
     if (!f) die("cannot create " + path);
+    static const unsigned char header[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
+    if (!g_members && fwrite(header, 1, 10, f) != 10) die("write error on " + path);
     std::atomic<uint64_t> next{0};
     std::mutex m;
     std::condition_variable cv;
-    uint64_t next_write = 0;
+    uint64_t next_write = 0, total_len = 0;
+    uLong total_crc = crc32(0, nullptr, 0);
     bool failed = false;
     auto worker = [&]() {
         std::string text;
@@ -59,18 +66,25 @@ static void write_gz_chunks(const std::string &path, uint64_t n_chunks, int thre
             make(c, text);
             z_stream zs;
             memset(&zs, 0, sizeof(zs));
-            if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) die("deflateInit2 failed");
+            if (deflateInit2(&zs, level, Z_DEFLATED, g_members ? 15 + 16 : -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) die("deflateInit2 failed");
             out.resize(deflateBound(&zs, (uLong)text.size()) + 64);
             zs.next_in = (Bytef *)text.data();
             zs.avail_in = (uInt)text.size();
             zs.next_out = out.data();
             zs.avail_out = (uInt)out.size();
-            if (deflate(&zs, Z_FINISH) != Z_STREAM_END) die("deflate failed");
+            const bool last = g_members || c + 1 == n_chunks;
+            const int rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
+            if ((last && rc != Z_STREAM_END) || (!last && (rc != Z_OK || zs.avail_in != 0 || zs.avail_out == 0))) die("deflate failed");
             const size_t n_out = out.size() - zs.avail_out;
             deflateEnd(&zs);
+            const uLong piece_crc = g_members ? 0 : crc32(crc32(0, nullptr, 0), (const Bytef *)text.data(), (uInt)text.size());
             std::unique_lock<std::mutex> lk(m);
             cv.wait(lk, [&] { return next_write == c; });
             if (fwrite(out.data(), 1, n_out, f) != n_out) failed = true;
+            if (!g_members) {
+                total_crc = crc32_combine(total_crc, piece_crc, (z_off_t)text.size());
+                total_len += text.size();
+            }
             next_write++;
             cv.notify_all();
         }
@@ -78,6 +92,14 @@ static void write_gz_chunks(const std::string &path, uint64_t n_chunks, int thre
     std::vector<std::thread> pool;
     for (int t = 0; t < threads; t++) pool.emplace_back(worker);
     for (std::thread &t : pool) t.join();
+    if (!g_members) {
+        unsigned char tr[8];
+        for (int i = 0; i < 4; i++) {
+            tr[i] = (unsigned char)(total_crc >> (8 * i));
+            tr[4 + i] = (unsigned char)(total_len >> (8 * i));
+        }
+        if (fwrite(tr, 1, 8, f) != 8) failed = true;
+    }
     if (fclose(f) != 0 || failed) die("write error on " + path);
 }
 
@@ -162,6 +184,7 @@ int main(int argc, char **argv)
         else if (a == "--seed") seed = strtoull(val(), nullptr, 0);
         else if (a == "--threads") threads = atoi(val());
         else if (a == "--level") level = atoi(val());
+        else if (a == "--members") g_members = true;
         else if (a == "--samples") samples = atoi(val());
         else if (a == "--pairs") pairs = strtoull(val(), nullptr, 0);
         else if (a == "--read-len") read_len = (uint32_t)atoi(val());
