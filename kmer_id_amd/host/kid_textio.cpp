@@ -171,7 +171,7 @@ GzLineBlocks::GzLineBlocks(const std::string &path, size_t block_bytes, size_t d
     impl_->chunk_bytes = block_bytes < 2 * REF_LINE_LIMIT ? 2 * REF_LINE_LIMIT : block_bytes;
     const int nt = inflate_threads > 0 ? inflate_threads : g_inflate_threads.load();
     // (both throw when the file cannot be opened: exit 255 like the reference's gzread(NULL))
-    if (nt > 1) impl_->par.reset(new ParallelGz(path, nt, (size_t)2 << 20, impl_->chunk_bytes, HEAD));
+    if (nt > 1) impl_->par.reset(new ParallelGz(path, nt, (size_t)1 << 20, impl_->chunk_bytes, HEAD)); // (1 MiB pieces: profiles/r03/inflate_threads.txt)
     else impl_->gz.reset(new GzStream(path));
     impl_->depth = depth < 1 ? 1 : depth;
     impl_->th = std::thread([this] { impl_->run(); });

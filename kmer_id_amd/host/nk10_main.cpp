@@ -189,6 +189,7 @@ int main(int argc, char **argv)
         tm.gpu_build_s = t_gpu_ready - t_db_loaded;
         n_devices = devices.size();
         if (cache_writer.joinable()) cache_writer.join();
+        std::thread([old = std::move(ps)]() mutable { old = ProbeSet(); }).detach(); // (giving 1.7 GB back takes 0.1 s: not in the way of the first sample)
         ps = ProbeSet();
 
         // ---- find the samples (:992-1014): every directory entry whose name contains the R1 suffix
