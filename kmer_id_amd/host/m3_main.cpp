@@ -91,6 +91,7 @@ int main(int argc, char **argv)
         }
         std::vector<int32_t> parent;
         ProbeSet ps;
+        set_inflate_threads(threads >= 6 ? threads / 2 : 1); // (gzip inputs: pieces inflated side by side when there are threads for it)
         load_database(tname, pname, db_cache, k, num_targ, parent, ps);
         std::cout << "tree loaded" << std::endl;
         std::cout << ps.lines_parsed << " kmers loaded" << std::endl;
