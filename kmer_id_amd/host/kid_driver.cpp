@@ -2,6 +2,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -274,12 +275,37 @@ std::unique_ptr<ReadBatch> Prefetcher::next_any(size_t lo, size_t hi, size_t &wh
     }
 }
 
+// A FASTQ block's record index and its results travel through ONE buffer of text memory (page-locked once a front-end
+// has installed the library's allocator): [records | final target | start | stop].  Copies to and from pageable memory
+// would make every "asynchronous" call wait for the GPU.
+static int submit_fastq_block(kid_sample *sample, ReadBatch &b, HostBuf &io, uint64_t *ticket)
+{
+    FastqBlock &fb = *b.fq;
+    const size_t nr = b.size();
+    io.resize(nr * (sizeof(kid_fastq_rec) + 12) + 64);
+    kid_fastq_rec *recs = (kid_fastq_rec *)io.data();
+    memcpy(recs, fb.recs.data(), nr * sizeof(kid_fastq_rec));
+    uint32_t *fin = (uint32_t *)(recs + nr);
+    int32_t *start = (int32_t *)(fin + nr), *stop = start + nr;
+    return kid_classify_fastq_async(sample, (const uint8_t *)fb.text.data(), fb.used, recs, nr, fin, start, stop, ticket);
+}
+static void collect_fastq_block(ReadBatch &b, const HostBuf &io, std::vector<uint32_t> &final_targ)
+{
+    const size_t nr = b.size();
+    const uint32_t *fin = (const uint32_t *)((const kid_fastq_rec *)io.data() + nr);
+    const int32_t *start = (const int32_t *)(fin + nr), *stop = start + nr;
+    final_targ.assign(fin, fin + nr);
+    b.start.assign(start, start + nr);
+    b.stop.assign(stop, stop + nr);
+}
+
 void run_files_together(Engine &e, Prefetcher &pf, size_t first, size_t count, ReadSaver &saver, std::vector<long long> &handed,
                         const std::function<void(size_t)> &done)
 {
     struct InFlight {
         std::unique_ptr<ReadBatch> batch;
         std::vector<uint32_t> final_targ;
+        HostBuf io;
         uint64_t ticket = 0;
         kid_sample *sample = nullptr;
         size_t file = 0;
@@ -304,6 +330,7 @@ void run_files_together(Engine &e, Prefetcher &pf, size_t first, size_t count, R
         int rc = kid_classify_wait(f.sample, f.ticket);
         e.gpu_wait_s += seconds_since(t0);
         if (rc != KID_OK) die_kid(rc);
+        if (f.batch->fq) collect_fastq_block(*f.batch, f.io, f.final_targ);
         handed[f.file] += saver.add_batch_of(f.file, *f.batch, f.final_targ, e.k);
         pending[f.file]--;
         q.pop_front();
@@ -320,18 +347,14 @@ void run_files_together(Engine &e, Prefetcher &pf, size_t first, size_t count, R
             f.file = which - first;
             pending[f.file]++;
             const size_t nr = f.batch->size();
-            f.final_targ.resize(nr);
             f.sample = e.samples[e.next_sample]; // batches are dealt round-robin over the devices
             e.next_sample = (e.next_sample + 1) % e.samples.size();
             int rc;
             const auto t_sub = std::chrono::steady_clock::now();
             if (f.batch->fq) {
-                FastqBlock &fb = *f.batch->fq;
-                f.batch->start.resize(nr);
-                f.batch->stop.resize(nr);
-                rc = kid_classify_fastq_async(f.sample, (const uint8_t *)fb.text.data(), fb.used, fb.recs.data(), nr, f.final_targ.data(),
-                                              f.batch->start.data(), f.batch->stop.data(), &f.ticket);
+                rc = submit_fastq_block(f.sample, *f.batch, f.io, &f.ticket);
             } else {
+                f.final_targ.resize(nr);
                 rc = kid_classify_batch_async(f.sample, f.batch->bases.data(), f.batch->offsets.data(), f.batch->start.data(),
                                               f.batch->stop.data(), nr, f.final_targ.data(), &f.ticket);
             }
@@ -359,6 +382,7 @@ long long run_file(Engine &e, Prefetcher &pf, size_t index, ReadSaver &saver)
     struct InFlight {
         std::unique_ptr<ReadBatch> batch;
         std::vector<uint32_t> final_targ;
+        HostBuf io;
         uint64_t ticket = 0;
         kid_sample *sample = nullptr;
     };
@@ -371,6 +395,7 @@ long long run_file(Engine &e, Prefetcher &pf, size_t index, ReadSaver &saver)
         int rc = kid_classify_wait(f.sample, f.ticket);
         e.gpu_wait_s += seconds_since(t0);
         if (rc != KID_OK) die_kid(rc);
+        if (f.batch->fq) collect_fastq_block(*f.batch, f.io, f.final_targ);
         n += saver.add_batch(*f.batch, f.final_targ, e.k);
         q.pop_front();
     };
@@ -380,18 +405,14 @@ long long run_file(Engine &e, Prefetcher &pf, size_t index, ReadSaver &saver)
             InFlight &f = q.back();
             f.batch = std::move(b);
             const size_t nr = f.batch->size();
-            f.final_targ.resize(nr);
             f.sample = e.samples[e.next_sample]; // batches are dealt round-robin over the devices
             e.next_sample = (e.next_sample + 1) % e.samples.size();
             int rc;
             const auto t_sub = std::chrono::steady_clock::now();
             if (f.batch->fq) {
-                FastqBlock &fb = *f.batch->fq;
-                f.batch->start.resize(nr);
-                f.batch->stop.resize(nr);
-                rc = kid_classify_fastq_async(f.sample, (const uint8_t *)fb.text.data(), fb.used, fb.recs.data(), nr, f.final_targ.data(),
-                                              f.batch->start.data(), f.batch->stop.data(), &f.ticket);
+                rc = submit_fastq_block(f.sample, *f.batch, f.io, &f.ticket);
             } else {
+                f.final_targ.resize(nr);
                 rc = kid_classify_batch_async(f.sample, f.batch->bases.data(), f.batch->offsets.data(), f.batch->start.data(),
                                               f.batch->stop.data(), nr, f.final_targ.data(), &f.ticket);
             }

@@ -47,13 +47,15 @@ void HostBuf::resize(size_t n)
     reset();
     {
         std::lock_guard<std::mutex> lk(g_pool.m);
+        size_t best = g_pool.spare.size(); // the smallest one that is large enough (text blocks and small buffers share the pool)
         for (size_t i = 0; i < g_pool.spare.size(); i++)
-            if (g_pool.spare[i].second >= n) {
-                p_ = g_pool.spare[i].first;
-                cap_ = g_pool.spare[i].second;
-                g_pool.spare.erase(g_pool.spare.begin() + (long)i);
-                return;
-            }
+            if (g_pool.spare[i].second >= n && (best == g_pool.spare.size() || g_pool.spare[i].second < g_pool.spare[best].second)) best = i;
+        if (best < g_pool.spare.size() && g_pool.spare[best].second <= 4 * n + (1 << 16)) {
+            p_ = g_pool.spare[best].first;
+            cap_ = g_pool.spare[best].second;
+            g_pool.spare.erase(g_pool.spare.begin() + (long)best);
+            return;
+        }
     }
     void *p = g_pool.alloc(n);
     if (!p) throw Fatal{1, "out of memory for a text block"};
