@@ -680,9 +680,10 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
         // the hit log: for the minimizer-localised table (its resolver is the one that logs), bitmaps of up to 1024 pieces
         const uint64_t nbins = (db->seen_bits + (1ull << KID_LOG_BIN_BITS) - 1) >> KID_LOG_BIN_BITS;
         if (db->d.minloc && nbins <= 1024) {
-            uint64_t cap = db->info.n_entries / 4;                    // per region: the whole log holds 2 x the entries ...
-            cap = cap < 4096 ? 4096 : cap > (16u << 20) ? (16u << 20) : cap; // ... at most 128 M hits = 512 MiB (+ as much to sort them)
-            cap &= ~63ull;
+            uint64_t total = db->info.n_entries * 2ull;              // the whole log holds 2 x the entries of the database ...
+            if (total < (32ull << 20)) total = 32ull << 20;          // ... at least 32 M (a launch of 1 M pairs with 16 hits per read) ...
+            if (total > (128ull << 20)) total = 128ull << 20;        // ... at most 128 M hits = 512 MiB (+ as much to sort them)
+            uint64_t cap = (total / KID_LOG_SHARDS) & ~63ull;        // per region
             s->seen_log_cap = (uint32_t)cap;
             s->log_nbins = (uint32_t)nbins;
             KID_S_HIP(hipMalloc(&s->seen_log, cap * KID_LOG_SHARDS * 4));

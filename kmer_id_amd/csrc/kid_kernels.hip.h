@@ -171,10 +171,12 @@ struct KidRareArgs {
     uint32_t seen_log_cap;
     uint32_t pad2;
 };
-#define KID_LOG_SHARDS 8u       // one region per XCD (blockIdx & 7): ~5 k fetch-and-adds per launch and counter
+#define KID_LOG_SHARDS 64u      // regions (blockIdx & 63), each with its own fill counter: a resolver chunk costs one fetch-and-add on
+                                // its region's counter, and with 16 hits per read (reads from genomes the database holds) there are
+                                // 600 k chunks per 1 M pairs -- on 8 counters they queued for 3 ms (profiles/r03/clumped_db_log_shards.txt)
 #define KID_LOG_NONE 0xFFFFFFFFu // a log place whose lookup turned out not to be a hit
 #define KID_LOG_BIN_BITS 18     // the apply pass owns the bitmap in pieces of 2^18 bits = 32 KiB of LDS
-#define KID_LOG_WGS 1024u       // workgroups of the counting / scattering kernels: 128 per region (a share = ~50 k entries)
+#define KID_LOG_WGS 1024u       // workgroups of the counting / scattering kernels: 16 per region
 
 // ------------------------------------------------------------------ hash lookup
 // Hashtable::getHash, newkmer_10nx.cpp:204-233 (+ probe cap kmer_read_m3.cpp:232)
@@ -2059,7 +2061,7 @@ struct KidLogArgs {
     uint64_t seen_words;
     unsigned long long *host_total; // mapped host memory: entries of this pass (the host paces the passes by it)
 };
-// the share of the log a counting / scattering workgroup owns: region blockIdx / 128, 1/128 of its entries (whole
+// the share of the log a counting / scattering workgroup owns: region blockIdx / 16, 1/16 of its entries (whole
 // groups of 64 entries: a share starts on a 16-byte boundary)
 __device__ __forceinline__ void kid_log_share(const KidLogArgs &a, uint32_t &begin, uint32_t &end)
 {

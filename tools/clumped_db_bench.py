@@ -58,82 +58,93 @@ def kmers(codes):
     return np.minimum(f, r)
 
 
-t0 = time.time()
-# taxonomy: 1 = root, then genera, species, strains
-parent = [1, 1]
-genomes, strain_t, species_t, genus_t = [], [], [], []
-for gi in range(G):
-    parent.append(1); gt = len(parent) - 1
-    anc = rng.integers(0, 4, GLEN).astype(np.uint8)
-    for si in range(S):
-        parent.append(gt); st = len(parent) - 1
-        sp = mutate(anc, 0.04, 0)
-        for ti in range(T):
-            parent.append(st); tt = len(parent) - 1
-            genomes.append(mutate(sp, 0.004, 6))
-            strain_t.append(tt); species_t.append(st); genus_t.append(gt)
-parent = np.array(parent, np.int32)
-ntar = parent.size
-# k-mer -> LCA
-keys_all = [kmers(g) for g in genomes]
-occ_key = np.concatenate(keys_all)
-occ_gen = np.concatenate([np.full(k_.size, i, np.int32) for i, k_ in enumerate(keys_all)])
-order = np.argsort(occ_key, kind="stable")
-sk = occ_key[order]
-sg = occ_gen[order]
-first = np.concatenate([[True], sk[1:] != sk[:-1]])
-starts = np.flatnonzero(first)
-ukeys = sk[starts]
-st_arr, sp_arr, ge_arr = np.array(strain_t)[sg], np.array(species_t)[sg], np.array(genus_t)[sg]
+CACHE = os.environ.get("CLUMPED_CACHE")  # (several library builds on the same database: the 3 minutes of numpy above once)
+if CACHE and os.path.exists(CACHE):
+    z = np.load(CACHE)
+    keys, targets, parent, reads_g, reads_r, rkeys = z["keys"], z["targets"], z["parent"], z["reads_g"], z["reads_r"], z["rkeys"]
+    n, L, n_reads = keys.size, 150, reads_g.shape[0]
+    log2_slots = max(16, int(np.ceil(np.log2(n / 0.10))))
+    dev = torch.device("cuda", 0)
+    print("clumped DB from %s: %d probes" % (CACHE, n), flush=True)
+else:
+    t0 = time.time()
+    # taxonomy: 1 = root, then genera, species, strains
+    parent = [1, 1]
+    genomes, strain_t, species_t, genus_t = [], [], [], []
+    for gi in range(G):
+        parent.append(1); gt = len(parent) - 1
+        anc = rng.integers(0, 4, GLEN).astype(np.uint8)
+        for si in range(S):
+            parent.append(gt); st = len(parent) - 1
+            sp = mutate(anc, 0.04, 0)
+            for ti in range(T):
+                parent.append(st); tt = len(parent) - 1
+                genomes.append(mutate(sp, 0.004, 6))
+                strain_t.append(tt); species_t.append(st); genus_t.append(gt)
+    parent = np.array(parent, np.int32)
+    ntar = parent.size
+    # k-mer -> LCA
+    keys_all = [kmers(g) for g in genomes]
+    occ_key = np.concatenate(keys_all)
+    occ_gen = np.concatenate([np.full(k_.size, i, np.int32) for i, k_ in enumerate(keys_all)])
+    order = np.argsort(occ_key, kind="stable")
+    sk = occ_key[order]
+    sg = occ_gen[order]
+    first = np.concatenate([[True], sk[1:] != sk[:-1]])
+    starts = np.flatnonzero(first)
+    ukeys = sk[starts]
+    st_arr, sp_arr, ge_arr = np.array(strain_t)[sg], np.array(species_t)[sg], np.array(genus_t)[sg]
 
 
-def same(a):
-    return np.minimum.reduceat(a, starts) == np.maximum.reduceat(a, starts)
+    def same(a):
+        return np.minimum.reduceat(a, starts) == np.maximum.reduceat(a, starts)
 
 
-lca = np.where(same(st_arr), np.minimum.reduceat(st_arr, starts),
-               np.where(same(sp_arr), np.minimum.reduceat(sp_arr, starts),
-                        np.where(same(ge_arr), np.minimum.reduceat(ge_arr, starts), 1))).astype(np.uint32)
-del occ_key, occ_gen, order, sk, sg, st_arr, sp_arr, ge_arr
-# emission: per genome, greedy non-overlapping walk over the positions whose k-mer has a target > 1
-pcount = np.zeros(ntar, np.int64)
-out_keys, out_targets = [], []
-for gi, kk in enumerate(keys_all):
-    tg = lca[np.searchsorted(ukeys, kk)]
-    elig = np.flatnonzero(tg > 1)
-    p = 0
-    pos = []
-    while True:
-        j = np.searchsorted(elig, p)
-        if j >= elig.size:
-            break
-        q = int(elig[j])
-        if pcount[tg[q]] < 100000:
-            pos.append(q)
-            pcount[tg[q]] += 1
-            p = q + K + 1  # the next probe ENDS at least KSIZE + 1 later: minpos = gpos + KSIZE, test gpos > minpos
-        else:
-            p = q + 1
-    pos = np.array(pos, np.int64)
-    out_keys.append(kk[pos]); out_targets.append(tg[pos])
-keys = np.concatenate(out_keys)
-targets = np.concatenate(out_targets)
-n = keys.size
-nu = np.unique(keys).size
-print("clumped DB: %d genomes x %d bases, %d nodes, %d probes (%d distinct keys) in %.0f s" % (len(genomes), GLEN, ntar, n, nu, time.time() - t0), flush=True)
-log2_slots = max(16, int(np.ceil(np.log2(n / 0.10))))
-rkeys = rng.integers(0, 1 << 60, n, dtype=np.uint64)  # random keys (canonical or not: lookups of random reads never hit either way)
-dev = torch.device("cuda", 0)
-n_reads, L = 2_000_000, 150
-Gm = [g for g in genomes]
-gi = rng.integers(0, len(Gm), n_reads)
-reads_g = np.empty((n_reads, L), np.uint8)
-lut = np.frombuffer(b"ACGT", np.uint8)
-for i in range(len(Gm)):
-    m = np.flatnonzero(gi == i)
-    pos = rng.integers(0, Gm[i].size - L + 1, m.size)
-    reads_g[m] = lut[Gm[i][pos[:, None] + np.arange(L)[None, :]]]
-reads_r = lut[rng.integers(0, 4, (n_reads, L))].astype(np.uint8)
+    lca = np.where(same(st_arr), np.minimum.reduceat(st_arr, starts),
+                   np.where(same(sp_arr), np.minimum.reduceat(sp_arr, starts),
+                            np.where(same(ge_arr), np.minimum.reduceat(ge_arr, starts), 1))).astype(np.uint32)
+    del occ_key, occ_gen, order, sk, sg, st_arr, sp_arr, ge_arr
+    # emission: per genome, greedy non-overlapping walk over the positions whose k-mer has a target > 1
+    pcount = np.zeros(ntar, np.int64)
+    out_keys, out_targets = [], []
+    for gi, kk in enumerate(keys_all):
+        tg = lca[np.searchsorted(ukeys, kk)]
+        elig = np.flatnonzero(tg > 1)
+        p = 0
+        pos = []
+        while True:
+            j = np.searchsorted(elig, p)
+            if j >= elig.size:
+                break
+            q = int(elig[j])
+            if pcount[tg[q]] < 100000:
+                pos.append(q)
+                pcount[tg[q]] += 1
+                p = q + K + 1  # the next probe ENDS at least KSIZE + 1 later: minpos = gpos + KSIZE, test gpos > minpos
+            else:
+                p = q + 1
+        pos = np.array(pos, np.int64)
+        out_keys.append(kk[pos]); out_targets.append(tg[pos])
+    keys = np.concatenate(out_keys)
+    targets = np.concatenate(out_targets)
+    n = keys.size
+    nu = np.unique(keys).size
+    print("clumped DB: %d genomes x %d bases, %d nodes, %d probes (%d distinct keys) in %.0f s" % (len(genomes), GLEN, ntar, n, nu, time.time() - t0), flush=True)
+    log2_slots = max(16, int(np.ceil(np.log2(n / 0.10))))
+    rkeys = rng.integers(0, 1 << 60, n, dtype=np.uint64)  # random keys (canonical or not: lookups of random reads never hit either way)
+    dev = torch.device("cuda", 0)
+    n_reads, L = 2_000_000, 150
+    Gm = [g for g in genomes]
+    gi = rng.integers(0, len(Gm), n_reads)
+    reads_g = np.empty((n_reads, L), np.uint8)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    for i in range(len(Gm)):
+        m = np.flatnonzero(gi == i)
+        pos = rng.integers(0, Gm[i].size - L + 1, m.size)
+        reads_g[m] = lut[Gm[i][pos[:, None] + np.arange(L)[None, :]]]
+    reads_r = lut[rng.integers(0, 4, (n_reads, L))].astype(np.uint8)
+    if CACHE:
+        np.savez(CACHE, keys=keys, targets=targets, parent=parent, reads_g=reads_g, reads_r=reads_r, rkeys=rkeys)
 for name, kk in (("clumped (builder-shaped)", keys), ("random keys", rkeys)):
     db = KmerDB(kk, targets, parent, k=K, log2_slots=log2_slots)
     info = db.info
