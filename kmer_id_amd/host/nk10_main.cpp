@@ -104,6 +104,16 @@ int main(int argc, char **argv)
         bool from_cache = false;
         std::thread cache_writer; // (a cache that has to be written is written beside the upload and the table build)
         struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } join_cache_writer{cache_writer};
+        // the HIP runtime takes 0.1-0.15 s to come up: while the database is being read, not after
+        std::thread gpu_warm;
+        Joiner join_gpu_warm{gpu_warm};
+        if (dry_run.empty() && !parse_only) {
+            const int warm_device = device_list.empty() ? device : atoi(device_list.c_str());
+            gpu_warm = std::thread([warm_device] {
+                void *p = nullptr;
+                if (kid_host_alloc(warm_device, 4096, &p) == KID_OK) kid_host_free(p);
+            });
+        }
         load_database(tpath, pname, db_cache, k, ntar, parent, ps, &from_cache, threads, &tm, &cache_writer);
         const double t_db_loaded = since_start();
         double t_gpu_ready = -1, t_first_file = -1;
@@ -177,6 +187,7 @@ int main(int argc, char **argv)
         Engine eng;
         eng.batch_reads = batch_reads;
         const std::vector<int> devices = device_list.empty() ? std::vector<int>(1, device) : parse_devices(device_list);
+        if (gpu_warm.joinable()) gpu_warm.join();
         if (!engine_open(eng, ps, parent, k, log2_slots, 0, 0, devices)) { // :256-260
             std::cout << "out of memory in table " << std::endl;
             return 1;
@@ -189,7 +200,17 @@ int main(int argc, char **argv)
         tm.gpu_build_s = t_gpu_ready - t_db_loaded;
         n_devices = devices.size();
         if (cache_writer.joinable()) cache_writer.join();
-        std::thread([old = std::move(ps)]() mutable { old = ProbeSet(); }).detach(); // (giving 1.7 GB back takes 0.1 s: not in the way of the first sample)
+        // The probe arrays (1.7 GB of address space) go back when the first sample is through: unmapping them takes 0.1 s
+        // during which no other thread of the process can map or page-lock memory -- which is what the first blocks of
+        // the first sample need.  (A run that ends before that leaves them to the operating system.)
+        struct Release { std::mutex m; std::condition_variable cv; bool now = false; };
+        static Release &release = *new Release(); // (never destroyed: the waiting thread may outlive main)
+        std::thread([old = std::move(ps)]() mutable {
+            std::unique_lock<std::mutex> lk(release.m);
+            release.cv.wait(lk, [] { return release.now; });
+            lk.unlock();
+            old = ProbeSet();
+        }).detach();
         ps = ProbeSet();
 
         // ---- find the samples (:992-1014): every directory entry whose name contains the R1 suffix
@@ -313,6 +334,11 @@ int main(int argc, char **argv)
                 outs[f].done = true;
                 if (failed) abort_run = true;
                 ocv.notify_all();
+                {
+                    std::lock_guard<std::mutex> rl(release.m);
+                    release.now = true;
+                    release.cv.notify_all();
+                }
             }
         };
         std::vector<std::thread> pool;

@@ -110,6 +110,36 @@ def test_dry_run_host_stages(nk10, gold_dir, tmp_path, kat):
     assert sum(len(v) for v in files.values()) > 700
 
 
+def test_host_stages_with_threads_on_one_stream(nk10, tmp_path):
+    """The probes file and the FASTQ files as single gzip members large enough to be inflated in pieces
+    (kmer_id_amd/host/kid_pargz.cpp): what the host stages make of them must not depend on the number of threads."""
+    tool = _build.build_tools()
+    cwd = str(tmp_path)
+    parent, cnt = synth.load_taxonomy("bact10")
+    os.makedirs(os.path.join(cwd, "bact10"))
+    with open(os.path.join(cwd, "counts.txt"), "w") as fh:
+        fh.write("".join("%d,%d\n" % (t, c) for t, c in enumerate(cnt.tolist())))
+    tree = os.path.join(cwd, "bact10", "btree_10.txt")
+    with open(tree, "w") as fh:
+        fh.write("".join("%d\t%d\n" % (x, y) for y, x in enumerate(parent.tolist()) if y >= 2 and x != 1))
+    open(os.path.join(cwd, "bact10", "bData10.txt"), "w").write("4\tX\n")
+    counts = os.path.join(cwd, "counts.txt")
+    subprocess.check_call([tool, "probes", "--counts", counts, "--scale", "0.01", "--level", "6", "--out",
+                           os.path.join(cwd, "bact10", "probes10.txt.gz")], stderr=subprocess.DEVNULL)
+    fq = os.path.join(cwd, "fq") + "/"
+    os.makedirs(fq)
+    subprocess.check_call([tool, "fastq", "--counts", counts, "--tree", tree, "--scale", "0.01", "--out-dir", fq, "--samples", "1",
+                           "--pairs", "60000", "--level", "6"], stderr=subprocess.DEVNULL)
+    assert os.path.getsize(os.path.join(cwd, "bact10", "probes10.txt.gz")) > (8 << 20)   # several 1 MiB pieces each
+    assert os.path.getsize(fq + "S0_R1_tr.fastq.gz") > (3 << 20)
+    dumps = []
+    for threads in (1, 8):
+        dump = os.path.join(cwd, "dry%d.txt" % threads)
+        subprocess.run([nk10, fq, "--dry-run", dump, "--threads", str(threads)], cwd=cwd, check=True, stdout=subprocess.PIPE)
+        dumps.append(open(dump, "rb").read())
+    assert len(dumps[0]) > (20 << 20) and dumps[0] == dumps[1]
+
+
 def test_fatal_inputs_exit_codes(nk10, tmp_path):
     cwd = str(tmp_path)
     make_db_dir(cwd, 2e-5)
