@@ -200,7 +200,7 @@ int main(int argc, char **argv)
         tm.gpu_build_s = t_gpu_ready - t_db_loaded;
         n_devices = devices.size();
         if (cache_writer.joinable()) cache_writer.join();
-        // The probe arrays (1.7 GB of address space) go back when the first sample is through: unmapping them takes 0.1 s
+        // The probe arrays (1.7 GB of address space) go back when the first sample is through and another follows: unmapping them takes 0.1 s
         // during which no other thread of the process can map or page-lock memory -- which is what the first blocks of
         // the first sample need.  (A run that ends before that leaves them to the operating system.)
         struct Release { std::mutex m; std::condition_variable cv; bool now = false; };
@@ -334,7 +334,7 @@ int main(int argc, char **argv)
                 outs[f].done = true;
                 if (failed) abort_run = true;
                 ocv.notify_all();
-                {
+                if (next_sample < n_samples) { // (more samples to come: now is the time; a run that is about to end leaves it to the exit)
                     std::lock_guard<std::mutex> rl(release.m);
                     release.now = true;
                     release.cv.notify_all();
