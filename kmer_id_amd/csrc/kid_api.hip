@@ -116,6 +116,7 @@ struct kid_sample {
     uint32_t seen_log_cap = 0, log_nbins = 0;
     unsigned long long *log_host_total = nullptr; // mapped host memory: entries of the last pass, written by the device
     bool log_dirty = false;            // something may have been logged since the last pass
+    bool log_off = false;              // this sample's reads hit so often that atomics from the resolver are cheaper (kid_seenlog_pace)
     uint32_t launches_since_apply = 0;
     uint64_t reads_since_apply = 0;
     double log_entries_per_read = 4.0; // pace of the passes: a guess until the first pass has reported
@@ -628,6 +629,7 @@ extern "C" void kid_sample_destroy(kid_sample *s)
     delete s;
 }
 
+static int kid_seenlog_point(kid_sample *s, uint32_t *log, hipStream_t stream);
 extern "C" int kid_sample_reset(kid_sample *s)
 {
     if (!s) return kid_fail(KID_ERR_ARG, "null sample");
@@ -645,6 +647,12 @@ extern "C" int kid_sample_reset(kid_sample *s)
     s->dev_clock_batches = 0;
     s->reads_submitted = 0;
     if (s->seen_log_tail) KID_HIP(hipMemset(s->seen_log_tail, 0, KID_LOG_SHARDS * 64));
+    if (s->log_off) {
+        int rc = kid_seenlog_point(s, s->seen_log, nullptr);
+        if (rc != KID_OK) return rc;
+        s->log_off = false;
+        s->log_entries_per_read = 4.0;
+    }
     s->log_dirty = false;
     s->launches_since_apply = 0;
     s->reads_since_apply = 0;
@@ -751,18 +759,43 @@ static int kid_seenlog_flush(kid_sample *s)
     KID_HIP(hipDeviceSynchronize());
     return kid_seenlog_apply(s, s->stream);
 }
+// the log pointer of every argument block of the sample (null: the resolvers set the bits with atomics), in stream order
+static int kid_seenlog_point(kid_sample *s, uint32_t *log, hipStream_t stream)
+{
+    KidRareArgs *blocks[kid_sample::NSET + 1];
+    int nb = 0;
+    for (kid_sample::Scratch &sc : s->sets) blocks[nb++] = sc.rare;
+    blocks[nb++] = s->rare_fixed;
+    for (int i = 0; i < nb; i++)
+        if (blocks[i]) {
+            uint32_t **where = &blocks[i]->seen_log;
+            if (log) KID_HIP(hipMemcpyAsync(where, &s->seen_log, sizeof(uint32_t *), hipMemcpyHostToDevice, stream));
+            else KID_HIP(hipMemsetAsync(where, 0, sizeof(uint32_t *), stream));
+        }
+    return KID_OK;
+}
 // before a launch of n_reads reads: run the pass if the log might not hold what the launch adds.  The device reports
 // the entries of every pass (mapped host memory, read without waiting: whatever pass has finished by now), from which
 // the hits per read of this sample are known; a region that does fill up falls back to atomics, so the pace only
 // matters for speed.
 static int kid_seenlog_pace(kid_sample *s, uint64_t n_reads, hipStream_t stream)
 {
-    if (!s->seen_log) return KID_OK;
+    if (!s->seen_log || s->log_off) return KID_OK;
     const unsigned long long seen_total = *(volatile unsigned long long *)s->log_host_total;
     if (seen_total != s->last_seen_host_total && s->reads_of_last_pass) {
         s->last_seen_host_total = seen_total;
         const double r = (double)seen_total / (double)s->reads_of_last_pass;
         s->log_entries_per_read = r > 0.01 ? r * 1.25 : 0.0125;
+        // Many hits per read (reads from genomes the database holds): neighbouring lookups name neighbouring bits, the
+        // resolver merges them over DPP and one atomic sets up to 16 -- cheaper than logging every hit and sorting the
+        // log (profiles/r03/dense_hits.txt: 15 hits per read 1-2 %, 60 hits 4.5 %, the builder-shaped database 6 %).
+        // The log stays for what has been logged; the launches from here on do without.  Until the sample is reset.
+        if (r > 8.0) {
+            int rc = kid_seenlog_point(s, nullptr, stream);
+            if (rc != KID_OK) return rc;
+            s->log_off = true;
+            return KID_OK;
+        }
     }
     const double room = 0.5 * (double)s->seen_log_cap * KID_LOG_SHARDS;
     if (s->log_dirty && ((double)(s->reads_since_apply + n_reads) * s->log_entries_per_read > room || s->launches_since_apply >= 256)) {

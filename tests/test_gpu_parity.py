@@ -858,6 +858,54 @@ def _genome_db(parent, n_genomes, genome_len, rng):
     return genomes, np.concatenate(keys), np.concatenate(targets)
 
 
+def test_many_hits_per_read_switch_the_hit_log_off_and_reset_switches_it_on():
+    """kmer_seen (newkmer_10nx.cpp:596-603) on a sample whose reads hit 100 times each: after the first pass over the
+    hit log has reported more than 8 entries per read, the library stops logging and the resolvers set the bits with
+    atomics (kid_seenlog_pace).  The counters must not notice: batches before the switch (logged), at it, behind it,
+    then the same sample reset and used for sparse reads again."""
+    parent, _ = synth.load_taxonomy("bact10")
+    rng = np.random.default_rng(4242)
+    genomes, keys, targets = _genome_db(parent, 120, 2500, rng)
+    odb = oracle_db(parent, keys, targets, 21)
+    db = KmerDB(keys, targets, parent, k=K, log2_slots=21)
+    L, n = 150, 40_000
+
+    def dense_batch():
+        gi = rng.integers(0, len(genomes), n)
+        pos = rng.integers(0, 2500 - L + 1, n)
+        return np.concatenate([genomes[g][p:p + L] for g, p in zip(gi, pos)])
+    off = synth.fixed_offsets(n, L)
+    s = db.sample()
+    os_ = ob.OracleSample(odb)
+    for step in range(5):
+        b = dense_batch()
+        assert np.array_equal(s.classify(b, off), os_.classify(b, off))
+        if step == 1:   # reading counters makes the library apply the log: the pass reports ~120 entries per read
+            eg, eu = os_.counts()
+            assert np.array_equal(s.gcount(), eg)
+            nb = s.seen_bytes()
+            assert np.array_equal(s.ucount_range(0, nb * 8), eu)
+    g, u = s.end()
+    eg, eu = os_.counts()
+    assert np.array_equal(g, eg) and np.array_equal(u, eu) and int(u.sum()) > 1000
+    # the same sample again, sparse reads: the log is back (nothing to see from outside but the counters)
+    s.reset()
+    os2 = ob.OracleSample(odb)
+    sparse = rng.choice(np.frombuffer(b"ACGT", np.uint8), n * L)
+    view = sparse.reshape(n, L)
+    few = rng.integers(0, n, 2000)
+    for r in few:
+        g_ = genomes[int(rng.integers(0, len(genomes)))]
+        p_ = int(rng.integers(0, 2500 - 40))
+        view[r, 10:50] = g_[p_:p_ + 40]
+    for _ in range(2):
+        assert np.array_equal(s.classify(sparse, off), os2.classify(sparse, off))
+    g, u = s.end()
+    eg, eu = os2.counts()
+    assert np.array_equal(g, eg) and np.array_equal(u, eu) and int(g[2:].sum()) > 0
+    s.close(); db.close()
+
+
 @pytest.mark.parametrize("read_len", [150, 157, 100, 250, 285, 286])
 def test_dense_hits_through_the_lookup_queue(read_len):
     """Reads cut from genomes whose every k-mer is in the DB: up to 128 queued lookups per read, runs
