@@ -116,7 +116,8 @@ struct kid_sample {
     uint32_t seen_log_cap = 0, log_nbins = 0;
     unsigned long long *log_host_total = nullptr; // mapped host memory: entries of the last pass, written by the device
     bool log_dirty = false;            // something may have been logged since the last pass
-    bool log_off = false;              // this sample's reads hit so often that atomics from the resolver are cheaper (kid_seenlog_pace)
+    bool log_off = false;              // a pass has found this sample's reads to hit so often that atomics from the resolver are cheaper
+    uint32_t passes_done = 0;
     uint32_t launches_since_apply = 0;
     uint64_t reads_since_apply = 0;
     double log_entries_per_read = 4.0; // pace of the passes: a guess until the first pass has reported
@@ -647,10 +648,12 @@ extern "C" int kid_sample_reset(kid_sample *s)
     s->dev_clock_batches = 0;
     s->reads_submitted = 0;
     if (s->seen_log_tail) KID_HIP(hipMemset(s->seen_log_tail, 0, KID_LOG_SHARDS * 64));
-    if (s->log_off) {
+    if (s->seen_log) { // (a pass may have taken the log out of the argument blocks: KidLogArgs)
         int rc = kid_seenlog_point(s, s->seen_log, nullptr);
         if (rc != KID_OK) return rc;
+        *(volatile unsigned int *)((char *)s->log_host_total + 8) = 0;
         s->log_off = false;
+        s->passes_done = 0;
         s->log_entries_per_read = 4.0;
     }
     s->log_dirty = false;
@@ -700,7 +703,7 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
             KID_S_HIP(hipMalloc(&s->log_counts, nbins * KID_LOG_WGS * 4));
             KID_S_HIP(hipMalloc(&s->log_bin_total, nbins * 4));
             KID_S_HIP(hipHostMalloc((void **)&s->log_host_total, 64, hipHostMallocMapped));
-            *s->log_host_total = 0;
+            memset((void *)s->log_host_total, 0, 64); // [0] entries of the last pass, [+8] "the pass switched the log off"
         }
         const KidRareArgs ra{s->gcount, s->stats, db->d.line_mask, 0u, 0ull, 0ull, 0, 0u, db->rows, s->seen, nullptr, nullptr,
                              s->seen_log, s->seen_log_tail, s->seen_log_cap, 0u};
@@ -738,7 +741,9 @@ static int kid_seenlog_apply(kid_sample *s, hipStream_t stream)
     void *dev_total = nullptr;
     KID_HIP(hipHostGetDevicePointer(&dev_total, s->log_host_total, 0));
     const KidLogArgs a{s->seen_log, s->seen_log_tail, s->seen_log_cap, s->log_nbins, s->log_counts, s->log_bin_total, s->seen_sorted,
-                       s->seen, s->seen_words, (unsigned long long *)dev_total};
+                       s->seen, s->seen_words, (unsigned long long *)dev_total, s->reads_since_apply,
+                       {s->sets[0].rare, s->sets[1].rare, s->sets[2].rare, s->rare_fixed}, (unsigned int *)((char *)dev_total + 8)};
+    static_assert(kid_sample::NSET == 3, "KidLogArgs::blocks");
     const uint32_t nb = s->log_nbins;
     hipLaunchKernelGGL(kid_seenlog_count_kernel, dim3(KID_LOG_WGS), dim3(256), nb * 4, stream, a);
     hipLaunchKernelGGL(kid_seenlog_scan_kernel, dim3(nb), dim3(KID_LOG_WGS), 0, stream, a);
@@ -750,6 +755,7 @@ static int kid_seenlog_apply(kid_sample *s, hipStream_t stream)
     s->log_dirty = false;
     s->launches_since_apply = 0;
     s->reads_since_apply = 0;
+    s->passes_done++;
     return KID_OK;
 }
 // ... when somebody wants to read the bitmap: behind everything the sample has queued anywhere (the caller synchronises after it)
@@ -781,21 +787,19 @@ static int kid_seenlog_point(kid_sample *s, uint32_t *log, hipStream_t stream)
 static int kid_seenlog_pace(kid_sample *s, uint64_t n_reads, hipStream_t stream)
 {
     if (!s->seen_log || s->log_off) return KID_OK;
+    if (*(volatile unsigned int *)((char *)s->log_host_total + 8)) { // a pass found more than 8 hits per read and took the log away (KidLogArgs)
+        s->log_off = true;
+        return KID_OK;
+    }
     const unsigned long long seen_total = *(volatile unsigned long long *)s->log_host_total;
     if (seen_total != s->last_seen_host_total && s->reads_of_last_pass) {
         s->last_seen_host_total = seen_total;
         const double r = (double)seen_total / (double)s->reads_of_last_pass;
         s->log_entries_per_read = r > 0.01 ? r * 1.25 : 0.0125;
-        // Many hits per read (reads from genomes the database holds): neighbouring lookups name neighbouring bits, the
-        // resolver merges them over DPP and one atomic sets up to 16 -- cheaper than logging every hit and sorting the
-        // log (profiles/r03/dense_hits.txt: 15 hits per read 1-2 %, 60 hits 4.5 %, the builder-shaped database 6 %).
-        // The log stays for what has been logged; the launches from here on do without.  Until the sample is reset.
-        if (r > 8.0) {
-            int rc = kid_seenlog_point(s, nullptr, stream);
-            if (rc != KID_OK) return rc;
-            s->log_off = true;
-            return KID_OK;
-        }
+    }
+    if (s->passes_done == 0 && s->log_dirty) { // behind a sample's first launch: what kind of sample it is should be known early
+        int rc = kid_seenlog_apply(s, stream);
+        if (rc != KID_OK) return rc;
     }
     const double room = 0.5 * (double)s->seen_log_cap * KID_LOG_SHARDS;
     if (s->log_dirty && ((double)(s->reads_since_apply + n_reads) * s->log_entries_per_read > room || s->launches_since_apply >= 256)) {

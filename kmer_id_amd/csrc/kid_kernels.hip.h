@@ -2060,6 +2060,14 @@ struct KidLogArgs {
     uint32_t *seen;
     uint64_t seen_words;
     unsigned long long *host_total; // mapped host memory: entries of this pass (the host paces the passes by it)
+    // Many hits per read (reads from genomes the database holds): neighbouring lookups name neighbouring bits, the
+    // resolver merges them over DPP and one atomic sets up to 16 -- cheaper than logging every hit and sorting the log
+    // (profiles/r03/dense_hits.txt: 15 hits per read 1-2 %, 60 hits 4.5 %, the builder-shaped database 6 %).  The
+    // pass decides: more than 8 hits per read of the `reads` it covers, and it takes the log out of the sample's
+    // argument blocks -- in stream order, in front of the next launch, without a trip to the host.
+    unsigned long long reads;
+    KidRareArgs *blocks[4];
+    unsigned int *off_flag;         // mapped host memory: set when the pass has switched the log off
 };
 // the share of the log a counting / scattering workgroup owns: region blockIdx / 16, 1/16 of its entries (whole
 // groups of 64 entries: a share starts on a 16-byte boundary)
@@ -2168,7 +2176,14 @@ __global__ __launch_bounds__(256) void kid_seenlog_scatter_kernel(const KidLogAr
     uint32_t *bases = kid_lh, *next = bases + nb + 1u, *hist = next + nb, *toff = hist + nb, *stage = toff + nb;
     __shared__ uint32_t wave_tot[5];
     const uint32_t total = kid_log_bin_bases(a, bases);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.host_total) *a.host_total = total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (a.host_total) *a.host_total = total;
+        if (a.reads && (unsigned long long)total > 8ull * a.reads) {
+            for (int i = 0; i < 4; i++)
+                if (a.blocks[i]) a.blocks[i]->seen_log = nullptr;
+            if (a.off_flag) *a.off_flag = 1u;
+        }
+    }
     for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) next[i] = bases[i] + a.counts[i * KID_LOG_WGS + blockIdx.x];
     uint32_t b0, b1;
     kid_log_share(a, b0, b1);
