@@ -2063,7 +2063,7 @@ struct KidLogArgs {
     // Many hits per read (reads from genomes the database holds): neighbouring lookups name neighbouring bits, the
     // resolver merges them over DPP and one atomic sets up to 16 -- cheaper than logging every hit and sorting the log
     // (profiles/r03/dense_hits.txt: 15 hits per read 1-2 %, 60 hits 4.5 %, the builder-shaped database 6 %).  The
-    // pass decides: more than 8 hits per read of the `reads` it covers, and it takes the log out of the sample's
+    // pass decides: more than 8 log places per read of the `reads` it covers, and it takes the log out of the sample's
     // argument blocks -- in stream order, in front of the next launch, without a trip to the host.
     unsigned long long reads;
     KidRareArgs *blocks[4];
@@ -2178,7 +2178,11 @@ __global__ __launch_bounds__(256) void kid_seenlog_scatter_kernel(const KidLogAr
     const uint32_t total = kid_log_bin_bases(a, bases);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (a.host_total) *a.host_total = total;
-        if (a.reads && (unsigned long long)total > 8ull * a.reads) {
+        // (by the places ASKED for -- hits, header matches that were none, and what no longer fitted: a log that
+        // overflows holds fewer entries than there were hits)
+        unsigned long long asked = 0;
+        for (uint32_t i = 0; i < KID_LOG_SHARDS; i++) asked += a.tail[i * 16u];
+        if (a.reads && asked > 8ull * a.reads) {
             for (int i = 0; i < 4; i++)
                 if (a.blocks[i]) a.blocks[i]->seen_log = nullptr;
             if (a.off_flag) *a.off_flag = 1u;
