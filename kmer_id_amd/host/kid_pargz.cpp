@@ -413,17 +413,24 @@ struct ParallelGz::Impl {
     uint8_t window[WIN];        // the last text in front of pos_bit (right-aligned)
     uint64_t parallel_bytes = 0;
 
-    struct Item {
-        bool is_member_end = false;
+    // A stretch of a piece's text on its way to the caller.  It may run over the ends of gzip members (a bgzip-style file
+    // has one every 64 KiB): the sums are kept per segment.
+    struct Segment {
+        size_t len = 0;          // text up to the member end (or the end of the item)
+        uint32_t crc = 0;        // ... its CRC-32 (the worker's part)
+        bool member_ends = false;
         uint32_t want_crc = 0, want_isize = 0;
-        // text
+    };
+    struct Item {
         HostBuf buf;
         size_t len = 0;
         bool ready = false;
-        uint32_t crc = 0;
+        std::vector<Segment> segs;
         std::shared_ptr<Chunk> chunk;
         size_t a = 0;
     };
+    bool has_pending_error = false;
+    Fatal pending_error{0, ""};
     std::deque<std::shared_ptr<Item>> items;
 
     void worker()
@@ -502,44 +509,49 @@ struct ParallelGz::Impl {
             memmove(window, window + c->n, WIN - c->n);
             for (size_t i = 0; i < c->n; i++) window[WIN - c->n + i] = c->table[c->sym[i]];
         }
-        // text and member ends in order; a text item never crosses a member end
+        // the text in stretches of up to piece_bytes, the member ends inside a stretch noted with it
         size_t at = 0, e = 0;
         while (at < c->n || e < c->ends.size()) {
-            const size_t upto = e < c->ends.size() ? c->ends[e].out_pos : c->n;
-            while (at < upto) {
-                std::shared_ptr<Item> it(new Item());
-                it->len = upto - at < piece_bytes ? upto - at : piece_bytes;
-                it->chunk = c;
-                it->a = at;
-                it->buf.resize(head + piece_bytes);
-                items.push_back(it);
-                {
-                    std::lock_guard<std::mutex> lk(m);
-                    urgent.push_back([this, it] {
-                        uint8_t *dst = (uint8_t *)it->buf.data() + head;
-                        const uint16_t *s = it->chunk->sym + it->a;
-                        const uint8_t *t = it->chunk->table;
-                        for (size_t i = 0; i < it->len; i++) dst[i] = t[s[i]];
-                        it->crc = crc32_fast(0, dst, it->len);
-                        it->chunk.reset();
-                        std::lock_guard<std::mutex> lk2(m);
-                        it->ready = true;
-                        cv_done.notify_all();
-                    });
-                    cv_work.notify_one();
+            std::shared_ptr<Item> it(new Item());
+            it->chunk = c;
+            it->a = at;
+            while (it->len < piece_bytes && (at < c->n || e < c->ends.size())) {
+                const size_t upto = e < c->ends.size() ? c->ends[e].out_pos : c->n;
+                Segment sg;
+                sg.len = upto - at < piece_bytes - it->len ? upto - at : piece_bytes - it->len;
+                at += sg.len;
+                it->len += sg.len;
+                accepted_member_out += sg.len;
+                if (e < c->ends.size() && c->ends[e].out_pos == at) {
+                    sg.member_ends = true;
+                    sg.want_crc = c->ends[e].crc;
+                    sg.want_isize = c->ends[e].isize;
+                    accepted_member_out = 0;
+                    e++;
                 }
-                at += it->len;
-                accepted_member_out += it->len;
-                parallel_bytes += it->len;
+                it->segs.push_back(sg);
             }
-            if (e < c->ends.size() && c->ends[e].out_pos == at) {
-                std::shared_ptr<Item> it(new Item());
-                it->is_member_end = true;
-                it->want_crc = c->ends[e].crc;
-                it->want_isize = c->ends[e].isize;
-                items.push_back(it);
-                accepted_member_out = 0;
-                e++;
+            parallel_bytes += it->len;
+            if (it->len) it->buf.resize(head + piece_bytes);
+            items.push_back(it);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                urgent.push_back([this, it] {
+                    uint8_t *dst = it->len ? (uint8_t *)it->buf.data() + head : nullptr;
+                    const uint16_t *s = it->chunk->sym + it->a;
+                    const uint8_t *t = it->chunk->table;
+                    for (size_t i = 0; i < it->len; i++) dst[i] = t[s[i]];
+                    size_t o = 0;
+                    for (Segment &sg : it->segs) {
+                        sg.crc = crc32_fast(0, dst + o, sg.len);
+                        o += sg.len;
+                    }
+                    it->chunk.reset();
+                    std::lock_guard<std::mutex> lk2(m);
+                    it->ready = true;
+                    cv_done.notify_all();
+                });
+                cv_work.notify_one();
             }
         }
         pos_bit = c->end_bit;
@@ -610,25 +622,33 @@ bool ParallelGz::next(HostBuf &buf, size_t &len)
             }
             z.accept_next();
         }
+        if (z.has_pending_error) throw z.pending_error;
         if (!z.items.empty()) { // hand out what is queued, in order
             std::shared_ptr<Impl::Item> it = z.items.front();
-            if (it->is_member_end) {
-                z.items.pop_front();
-                if (it->want_crc != z.crc) throw Fatal{255, z.path + ": incorrect data check"};
-                if (it->want_isize != (uint32_t)z.member_out) throw Fatal{255, z.path + ": incorrect length check"};
-                z.crc = 0;
-                z.member_out = 0;
-                continue;
-            }
             {
                 std::unique_lock<std::mutex> lk(z.m);
                 z.cv_done.wait(lk, [&] { return it->ready; });
             }
             z.items.pop_front();
-            z.crc = (uint32_t)crc32_combine(z.crc, it->crc, (z_off_t)it->len);
-            z.member_out += it->len;
+            size_t good = 0; // text in front of a member whose sums are wrong is handed out first, like the sequential reader does
+            for (const Impl::Segment &sg : it->segs) {
+                z.crc = (uint32_t)crc32_combine(z.crc, sg.crc, (z_off_t)sg.len);
+                z.member_out += sg.len;
+                good += sg.len;
+                if (!sg.member_ends) continue;
+                const char *what = sg.want_crc != z.crc ? "incorrect data check" : sg.want_isize != (uint32_t)z.member_out ? "incorrect length check" : nullptr;
+                if (what) {
+                    z.pending_error = Fatal{255, z.path + ": " + what};
+                    z.has_pending_error = true;
+                    z.items.clear();
+                    break;
+                }
+                z.crc = 0;
+                z.member_out = 0;
+            }
+            if (good == 0) continue; // (member ends only, or nothing in front of the damage)
             buf = std::move(it->buf);
-            len = it->len;
+            len = good;
             return true;
         }
         if (z.finished) return false;

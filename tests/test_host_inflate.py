@@ -121,6 +121,9 @@ def test_member_layouts(gzcat, tmp_path):
         "empty_file": b"",
         "python_gzip": gzip.compress(b, 9),
     }
+    # bgzip-style: a member every few KiB of text, each with an extra field, an empty member at the end
+    small = [member(t["probes"][i:i + 9000], extra=b"BC\x02\x00\x00\x00") for i in range(0, 400000, 9000)]
+    cases["many_small_members"] = b"".join(small) + member(b"", extra=b"BC\x02\x00\x1b\x00")
     for name, blob in cases.items():
         p = str(tmp_path / (name + ".gz"))
         open(p, "wb").write(blob)
@@ -133,6 +136,9 @@ def test_member_layouts(gzcat, tmp_path):
         "bad_crc": member(a)[:-8] + b"\0\0\0\0" + member(a)[-4:],
         "bad_length": member(a)[:-4] + b"\1\0\0\0",
         "second_member_damaged": member(a) + member(b)[:200] + b"\xff" * 50 + member(b)[250:],
+        # wrong sums in the middle of a file of many small members: the text in front of that member's end, then the error
+        "small_member_bad_crc": b"".join(small[:20]) + small[20][:-8] + b"\1\2\3\4" + small[20][-4:] + b"".join(small[21:]),
+        "small_member_bad_length": b"".join(small[:7]) + small[7][:-4] + b"\1\0\0\0" + b"".join(small[8:]),
     }
     for name, blob in bad.items():
         p = str(tmp_path / (name + ".gz"))
