@@ -10,7 +10,7 @@
 //   --db-dir DIR (./bact10/)  --ntar N (5982)  --k K (30)  --log2-slots L (30)  --device D (0)
 //   --devices A,B,...  several GPUs: the table is built on the first and replicated into the others' HBM, the batches of
 //                    a sample are dealt round-robin over them, the counters merged when the sample is closed
-//   --batch-reads N (262144)  --threads T (4: reader threads parsing files ahead)  --r1 SUFFIX (_R1_tr.fastq.gz)  --r2 SUFFIX (_R2_tr.fastq.gz)
+//   --batch-reads N (262144)  --threads T (the host's, at most 16: inflating, finding lines, parsing)  --r1 SUFFIX (_R1_tr.fastq.gz)  --r2 SUFFIX (_R2_tr.fastq.gz)
 //   --fasta          the reference's compile-time FASTQ=0 mode (:28,:1032-1035): one plain FASTA file
 //                    <prefix><r1 suffix> per sample, read by process_fa (:877-913), no R2 file
 //   --db-cache FILE  binary cache of the parsed database: read if valid, (re)written otherwise
@@ -39,7 +39,9 @@ using namespace kidhost;
 int main(int argc, char **argv)
 {
     std::string dname, db_dir = "./bact10/", e1 = "_R1_tr.fastq.gz", e2 = "_R2_tr.fastq.gz";
-    int ntar = 5982, k = 30, log2_slots = 30, device = 0, threads = 4;
+    int ntar = 5982, k = 30, log2_slots = 30, device = 0;
+    int threads = (int)std::thread::hardware_concurrency(); // (at most 16 unless --threads says otherwise)
+    threads = threads < 1 ? 1 : threads > 16 ? 16 : threads;
     size_t batch_reads = 1 << 18;
     std::string dry_run, db_cache, device_list;
     bool fasta_mode = false;
