@@ -138,6 +138,23 @@ def test_host_stages_with_threads_on_one_stream(nk10, tmp_path):
         subprocess.run([nk10, fq, "--dry-run", dump, "--threads", str(threads)], cwd=cwd, check=True, stdout=subprocess.PIPE)
         dumps.append(open(dump, "rb").read())
     assert len(dumps[0]) > (20 << 20) and dumps[0] == dumps[1]
+    # the same file cut off: everything in front is read, then "failed gzclose" (:815), exit 255
+    r1 = fq + "S0_R1_tr.fastq.gz"
+    whole = open(r1, "rb").read()
+
+    def dry(threads):
+        return subprocess.run([nk10, fq, "--dry-run", os.path.join(cwd, "bad.txt"), "--threads", str(threads)], cwd=cwd,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    open(r1, "wb").write(whole[:len(whole) * 3 // 5])
+    for threads in (1, 8):
+        r = dry(threads)
+        assert r.returncode == 255 and b"failed gzclose" in r.stderr, (threads, r.returncode, r.stderr[-300:])
+    # ... and damaged in the middle: what the damage inflates to is read like any text until the stream's own checks
+    # trip (exit 255, :776) -- or until a garbage record has a quality line shorter than its sequence (exit 134, as in
+    # the reference).  Whichever it is, it is the same with one thread and with eight.
+    open(r1, "wb").write(whole[:len(whole) // 2] + bytes(64) + whole[len(whole) // 2 + 64:])
+    a, b = dry(1), dry(8)
+    assert a.returncode in (134, 255) and (a.returncode, a.stderr) == (b.returncode, b.stderr), (a.returncode, b.returncode, a.stderr[-200:], b.stderr[-200:])
 
 
 def test_fatal_inputs_exit_codes(nk10, tmp_path):
