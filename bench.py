@@ -489,7 +489,7 @@ def main():
         if args.e2e_leg:
             log("nk10 FASTQ.gz leg ...")
             try:
-                e2e_leg = cli_e2e_leg(min(8, host_cores()))
+                e2e_leg = cli_e2e_leg(min(16, host_cores()))  # (one GPU's share of the pool's hosts)
             except Exception as e:  # the CLI leg must not take the metric down with it
                 e2e_leg = {"error": repr(e)}
 
