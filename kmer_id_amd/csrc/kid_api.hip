@@ -114,7 +114,7 @@ struct kid_sample {
     // scratch of the pass that turns them into bits of `seen`
     uint32_t *seen_log = nullptr, *seen_log_tail = nullptr, *seen_sorted = nullptr, *log_counts = nullptr, *log_bin_total = nullptr;
     uint32_t seen_log_cap = 0, log_nbins = 0;
-    unsigned long long *log_host_total = nullptr; // mapped host memory: entries of the last pass, written by the device
+    unsigned long long *log_host_total = nullptr; // mapped host memory: [0] log places per 1024 reads as of the last pass, [+8] "log off", written by the device
     bool log_dirty = false;            // something may have been logged since the last pass
     bool log_off = false;              // a pass has found this sample's reads to hit so often that atomics from the resolver are cheaper
     uint32_t passes_done = 0;
@@ -122,7 +122,6 @@ struct kid_sample {
     uint64_t reads_since_apply = 0;
     double log_entries_per_read = 4.0; // pace of the passes: a guess until the first pass has reported
     uint64_t reads_of_last_pass = 0;
-    unsigned long long last_seen_host_total = 0;
     // very long records: one word per k-mer position for the hits
     uint32_t *long_hits = nullptr;
     uint64_t long_hits_cap = 0;
@@ -652,6 +651,7 @@ extern "C" int kid_sample_reset(kid_sample *s)
         int rc = kid_seenlog_point(s, s->seen_log, nullptr);
         if (rc != KID_OK) return rc;
         *(volatile unsigned int *)((char *)s->log_host_total + 8) = 0;
+        *(volatile unsigned long long *)s->log_host_total = 0;
         s->log_off = false;
         s->passes_done = 0;
         s->log_entries_per_read = 4.0;
@@ -703,7 +703,7 @@ extern "C" int kid_sample_begin(kid_db *db, kid_sample **out)
             KID_S_HIP(hipMalloc(&s->log_counts, nbins * KID_LOG_WGS * 4));
             KID_S_HIP(hipMalloc(&s->log_bin_total, nbins * 4));
             KID_S_HIP(hipHostMalloc((void **)&s->log_host_total, 64, hipHostMallocMapped));
-            memset((void *)s->log_host_total, 0, 64); // [0] entries of the last pass, [+8] "the pass switched the log off"
+            memset((void *)s->log_host_total, 0, 64);
         }
         const KidRareArgs ra{s->gcount, s->stats, db->d.line_mask, 0u, 0ull, 0ull, 0, 0u, db->rows, s->seen, nullptr, nullptr,
                              s->seen_log, s->seen_log_tail, s->seen_log_cap, 0u};
@@ -791,11 +791,10 @@ static int kid_seenlog_pace(kid_sample *s, uint64_t n_reads, hipStream_t stream)
         s->log_off = true;
         return KID_OK;
     }
-    const unsigned long long seen_total = *(volatile unsigned long long *)s->log_host_total;
-    if (seen_total != s->last_seen_host_total && s->reads_of_last_pass) {
-        s->last_seen_host_total = seen_total;
-        const double r = (double)seen_total / (double)s->reads_of_last_pass;
-        s->log_entries_per_read = r > 0.01 ? r * 1.25 : 0.0125;
+    const unsigned long long rate = *(volatile unsigned long long *)s->log_host_total; // places per 1024 reads | 1 << 63, from the latest pass that has run
+    if (rate >> 63) {
+        const double r = (double)(rate & ~(1ull << 63)) / 1024.0;
+        s->log_entries_per_read = r > 0.01 ? r * 1.1 : 0.011;
     }
     // (A first pass right behind a sample's first launch would tell early what kind of sample it is -- and made every
     // later launch of the metric's workload 3 % slower, profiles/r03/ab_early_pass.txt; the first regular pass comes

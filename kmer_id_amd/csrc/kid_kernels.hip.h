@@ -2059,7 +2059,7 @@ struct KidLogArgs {
     uint32_t *sorted;
     uint32_t *seen;
     uint64_t seen_words;
-    unsigned long long *host_total; // mapped host memory: entries of this pass (the host paces the passes by it)
+    unsigned long long *host_total; // mapped host memory: log places asked for per 1024 reads, as of this pass (the host paces the passes by it)
     // Many hits per read (reads from genomes the database holds): neighbouring lookups name neighbouring bits, the
     // resolver merges them over DPP and one atomic sets up to 16 -- cheaper than logging every hit and sorting the log
     // (profiles/r03/dense_hits.txt: 15 hits per read 1-2 %, 60 hits 4.5 %, the builder-shaped database 6 %).  The
@@ -2177,11 +2177,12 @@ __global__ __launch_bounds__(256) void kid_seenlog_scatter_kernel(const KidLogAr
     __shared__ uint32_t wave_tot[5];
     const uint32_t total = kid_log_bin_bases(a, bases);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (a.host_total) *a.host_total = total;
         // (by the places ASKED for -- hits, header matches that were none, and what no longer fitted: a log that
-        // overflows holds fewer entries than there were hits)
+        // overflows holds fewer entries than there were hits.  Reported as ONE word, a rate: the host runs far ahead of
+        // the device, and a count would meet the wrong number of reads there)
         unsigned long long asked = 0;
         for (uint32_t i = 0; i < KID_LOG_SHARDS; i++) asked += a.tail[i * 16u];
+        if (a.host_total && a.reads) *a.host_total = ((asked << 10) / a.reads) | (1ull << 63);
         if (a.reads && asked > 8ull * a.reads) {
             for (int i = 0; i < 4; i++)
                 if (a.blocks[i]) a.blocks[i]->seen_log = nullptr;
