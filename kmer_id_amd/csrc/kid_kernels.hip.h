@@ -2175,7 +2175,7 @@ __global__ __launch_bounds__(256) void kid_seenlog_scatter_kernel(const KidLogAr
     const uint32_t nb = a.nbins;
     uint32_t *bases = kid_lh, *next = bases + nb + 1u, *hist = next + nb, *toff = hist + nb, *stage = toff + nb;
     __shared__ uint32_t wave_tot[5];
-    const uint32_t total = kid_log_bin_bases(a, bases);
+    kid_log_bin_bases(a, bases);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // (by the places ASKED for -- hits, header matches that were none, and what no longer fitted: a log that
         // overflows holds fewer entries than there were hits.  Reported as ONE word, a rate: the host runs far ahead of
