@@ -9,6 +9,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -141,12 +142,13 @@ bool code_is_usable(const uint8_t *lens, unsigned n, bool may_be_empty)
 }
 
 // The first bit position in [from_byte * 8, limit_byte * 8) where a dynamic block header that parses starts.
-uint64_t find_block(const uint8_t *file, size_t flen, uint64_t from_byte, uint64_t limit_byte)
+uint64_t find_block(const uint8_t *file, size_t flen, uint64_t from_byte, uint64_t limit_byte, const std::atomic<bool> &cancel)
 {
     if (flen < TAIL_MARGIN + 16) return NOWHERE;
     if (limit_byte > flen - TAIL_MARGIN) limit_byte = flen - TAIL_MARGIN;
     uint8_t lens[288 + 32];
     for (uint64_t byte = from_byte; byte < limit_byte; byte++) {
+        if ((byte & 4095u) == 0 && cancel.load(std::memory_order_relaxed)) return NOWHERE; // (nobody is going to ask)
         const uint64_t w = load64(file + byte);
         for (unsigned k = 0; k < 8; k++) {
             const uint64_t v = w >> k;
@@ -395,11 +397,13 @@ struct ParallelGz::Impl {
     std::condition_variable cv_work, cv_done;
     std::deque<std::function<void()>> urgent, normal;
     bool quit = false;
+    std::atomic<bool> cancel{false}; // the pieces still being looked for are not wanted any more
 
     // pieces of the file
     std::vector<std::shared_ptr<Chunk>> chunks; // [0] unused: the file starts with the sequential reader
     size_t submitted = 1, expect = 1;            // chunks [1, submitted) are with the workers; `expect` should start at `pos_bit`
     size_t ahead = 8;
+    unsigned unusable_in_a_row = 0; // pieces that did not continue the text in front of them (see accept_next)
 
     // the stream
     std::unique_ptr<GzStream> seq;
@@ -457,8 +461,8 @@ struct ParallelGz::Impl {
             chunks[submitted++] = c;
             std::lock_guard<std::mutex> lk(m);
             normal.push_back([this, c] {
-                c->start_bit = find_block(file, flen, c->from_byte, c->from_byte + 2 * chunk_bytes);
-                if (c->start_bit != NOWHERE) spec_decode(file, flen, *c, chunk_bytes * 16);
+                c->start_bit = find_block(file, flen, c->from_byte, c->from_byte + 2 * chunk_bytes, cancel);
+                if (c->start_bit != NOWHERE && !cancel.load()) spec_decode(file, flen, *c, chunk_bytes * 16);
                 std::lock_guard<std::mutex> lk2(m);
                 c->done = true;
                 cv_done.notify_all();
@@ -498,8 +502,16 @@ struct ParallelGz::Impl {
         if (c->start_bit != pos_bit || !reach_ok) { // not the continuation of what is in front: inflate this stretch in order
             seq_pending = true;
             seq_stop_byte = next_stop;
+            // A file that keeps doing this is not made of dynamic-code blocks (stored blocks: data that does not compress):
+            // looking for headers in it costs far more than reading it in order does.  The rest goes to the sequential reader.
+            if (++unusable_in_a_row >= 4) {
+                seq_stop_byte = NOWHERE;
+                expect = submitted = chunks.size();
+                cancel = true;
+            }
             return;
         }
+        unusable_in_a_row = 0;
         for (unsigned v = 0; v < 256; v++) c->table[v] = (uint8_t)v;
         memcpy(c->table + 256, window, WIN);
         // the text behind this piece's last 32 KiB: the window of the next
@@ -591,6 +603,7 @@ ParallelGz::ParallelGz(const std::string &path, int threads, size_t chunk_bytes,
 ParallelGz::~ParallelGz()
 {
     Impl &z = *impl_;
+    z.cancel = true;
     {
         std::lock_guard<std::mutex> lk(z.m);
         z.quit = true;
