@@ -403,7 +403,7 @@ struct ParallelGz::Impl {
     std::vector<std::shared_ptr<Chunk>> chunks; // [0] unused: the file starts with the sequential reader
     size_t submitted = 1, expect = 1;            // chunks [1, submitted) are with the workers; `expect` should start at `pos_bit`
     size_t ahead = 8;
-    unsigned unusable_in_a_row = 0; // pieces that did not continue the text in front of them (see accept_next)
+    unsigned unusable_in_a_row = 0, patience = 4; // pieces that did not continue the text in front of them (see accept_next)
 
     // the stream
     std::unique_ptr<GzStream> seq;
@@ -504,7 +504,7 @@ struct ParallelGz::Impl {
             seq_stop_byte = next_stop;
             // A file that keeps doing this is not made of dynamic-code blocks (stored blocks: data that does not compress):
             // looking for headers in it costs far more than reading it in order does.  The rest goes to the sequential reader.
-            if (++unusable_in_a_row >= 4) {
+            if (++unusable_in_a_row >= patience) {
                 seq_stop_byte = NOWHERE;
                 expect = submitted = chunks.size();
                 cancel = true;
@@ -575,9 +575,10 @@ struct ParallelGz::Impl {
     }
 };
 
-ParallelGz::ParallelGz(const std::string &path, int threads, size_t chunk_bytes, size_t piece_bytes, size_t head) : impl_(new Impl())
+ParallelGz::ParallelGz(const std::string &path, int threads, size_t chunk_bytes, size_t piece_bytes, size_t head, unsigned patience) : impl_(new Impl())
 {
     Impl &z = *impl_;
+    z.patience = patience < 1 ? 1 : patience;
     z.path = path;
     z.threads = threads;
     z.chunk_bytes = chunk_bytes < 4096 ? 4096 : chunk_bytes;

@@ -28,7 +28,9 @@ class ParallelGz {
 public:
     // chunk_bytes: compressed bytes per piece of the file; piece_bytes: most text handed out at a time;
     // head: bytes of headroom a handed-out buffer has in front of its text (>= 32768)
-    ParallelGz(const std::string &path, int threads, size_t chunk_bytes, size_t piece_bytes, size_t head);
+    // patience: after so many pieces in a row that did not fit, the rest of the file is read sequentially (stored
+    // blocks -- data that does not compress -- are read faster than headers are looked for in them)
+    ParallelGz(const std::string &path, int threads, size_t chunk_bytes, size_t piece_bytes, size_t head, unsigned patience = 4);
     ~ParallelGz();
     ParallelGz(const ParallelGz &) = delete;
     ParallelGz &operator=(const ParallelGz &) = delete;

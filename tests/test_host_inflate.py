@@ -51,10 +51,12 @@ def same_as_zlib(gzcat, path, rooms=(1 << 20,), cut_off=False):
             assert out == out_z and err == err_z, (path, room, err, err_z, len(out), len(out_z))
     # pieces of the file inflated side by side (kid_pargz.cpp): the sequential reader's text and failures, byte for byte
     rc, out, err = run(gzcat, path, "--room", "70000")
-    for threads, chunk in ((3, 4096), (2, 30000), (4, 1 << 20)):
-        rc_p, out_p, err_p = run(gzcat, path, "--threads", str(threads), "--chunk", str(chunk), "--room", "70000")
+    # (pieces of 4 KiB are smaller than a block: most of them do not fit and the stretch is read again in order --
+    # with patience for it, and with the default of 4 misfits in a row after which the rest is read sequentially)
+    for threads, chunk, patience in ((3, 4096, 1 << 20), (3, 4096, 4), (2, 30000, 4), (4, 1 << 20, 4)):
+        rc_p, out_p, err_p = run(gzcat, path, "--threads", str(threads), "--chunk", str(chunk), "--patience", str(patience), "--room", "70000")
         err_p = "\n".join(l for l in err_p.splitlines() if not l.startswith("parallel: "))
-        assert (rc_p, err_p) == (rc, err) and out_p == out, (path, threads, chunk, rc_p, rc, err_p, err, len(out_p), len(out))
+        assert (rc_p, err_p) == (rc, err) and out_p == out, (path, threads, chunk, patience, rc_p, rc, err_p, err, len(out_p), len(out))
     return rc_z, out_z, err_z
 
 

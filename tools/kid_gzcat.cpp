@@ -2,7 +2,7 @@
 // (kmer_id_amd/host/kid_inflate.cpp) or, with --zlib, by zlib's gzread the way the reference reads its files
 // (newkmer_10nx.cpp:762-816: 16 KiB calls).  tests/test_host_inflate.py compares the two on good, odd and damaged files.
 //   kid_gzcat [--zlib] [--room BYTES] [--time] FILE      (--time: no text; the best of three passes, as MB/s of text)
-//   kid_gzcat --threads N [--chunk BYTES] [--room BYTES] [--time] FILE     pieces of the file inflated side by side
+//   kid_gzcat --threads N [--chunk BYTES] [--patience P] [--room BYTES] [--time] FILE     pieces of the file inflated side by side
 //                                                         (kmer_id_amd/host/kid_pargz.cpp); "parallel: N bytes" on stderr
 // exit 0 = read to the end and closed; 3 = a read failed (message on stderr); 4 = the close failed ("failed gzclose").
 #include <stdio.h>
@@ -23,12 +23,14 @@ int main(int argc, char **argv)
     bool use_zlib = false, time_it = false;
     size_t room = (size_t)1 << 20, chunk = (size_t)2 << 20;
     int threads = 0;
+    unsigned patience = 4;
     const char *path = nullptr;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--zlib")) use_zlib = true;
         else if (!strcmp(argv[i], "--time")) time_it = true;
         else if (!strcmp(argv[i], "--threads") && i + 1 < argc) threads = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--chunk") && i + 1 < argc) chunk = (size_t)atol(argv[++i]);
+        else if (!strcmp(argv[i], "--patience") && i + 1 < argc) patience = (unsigned)atoi(argv[++i]);
         else if (!strcmp(argv[i], "--room") && i + 1 < argc) room = (size_t)atol(argv[++i]);
         else path = argv[i];
     }
@@ -49,7 +51,7 @@ int main(int argc, char **argv)
                 gzclose(g);
             } else if (threads > 0) {
                 try {
-                    kidhost::ParallelGz z(path, threads, chunk, room, kidhost::GzStream::kWindow);
+                    kidhost::ParallelGz z(path, threads, chunk, room, kidhost::GzStream::kWindow, patience);
                     kidhost::HostBuf buf;
                     size_t n;
                     while (z.next(buf, n)) total += n;
@@ -93,7 +95,7 @@ int main(int argc, char **argv)
     }
     if (threads > 0) {
         try {
-            kidhost::ParallelGz z(path, threads, chunk, room, kidhost::GzStream::kWindow);
+            kidhost::ParallelGz z(path, threads, chunk, room, kidhost::GzStream::kWindow, patience);
             kidhost::HostBuf buf;
             try {
                 size_t n;
